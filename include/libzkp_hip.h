@@ -1,0 +1,77 @@
+/* libzkp_hip -- C ABI of the MI355X (gfx950) proving backend for libzkp's Bulletproofs hot path.
+ *
+ * Drop-in boundary: these entry points are what the reference's Rust side binds through `extern "C"`
+ * in place of its CPU backend calls (binding sketch: INTEGRATION.md).  Plain pointers and sizes only.
+ * All calls are batch-first; a single proof is the n = 1 case.  Thread-safe: one internal context per
+ * process, calls are serialised on it.
+ *
+ * Randomness: the reference draws blindings from OsRng/thread_rng (bulletproofs.rs:82-87,132), so its
+ * proof bytes are not reproducible.  Here every op takes a 32-byte seed from which all of its random
+ * scalars are derived (tape definition: DESIGN.md); pass seeds = NULL to have the library draw fresh
+ * seeds from the OS RNG (the reference's behaviour).
+ *
+ * Status codes per item follow ZkpError (/root/reference/src/utils/error_handling.rs:8-18).
+ */
+#ifndef LIBZKP_HIP_H
+#define LIBZKP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZKP_HIP_RANGE_PROOF_BYTES 1478u      /* proof::range_proof::prove_range output, n_bits = 64 */
+#define ZKP_HIP_THRESHOLD_PROOF_BYTES 762u   /* proof::threshold_proof::prove_threshold output      */
+
+enum {
+    ZKP_HIP_OK = 0,
+    ZKP_HIP_INVALID_INPUT = 1,             /* ZkpError::InvalidInput          */
+    ZKP_HIP_PROOF_GENERATION_FAILED = 2,   /* ZkpError::ProofGenerationFailed */
+    ZKP_HIP_INVALID_PROOF_FORMAT = 4,      /* ZkpError::InvalidProofFormat    */
+    ZKP_HIP_BACKEND_ERROR = 5              /* ZkpError::BackendError          */
+};
+
+/* Library-level return values: 0 = every item succeeded, 1 = at least one item has status != 0
+ * (outputs of the other items are still valid), < 0 = the call itself failed (see zkp_hip_last_error). */
+#define ZKP_HIP_E_RUNTIME (-1)       /* HIP runtime error / no device / out of memory */
+#define ZKP_HIP_E_UNSUPPORTED (-2)   /* e.g. n_bits != 64 */
+#define ZKP_HIP_E_ARGUMENT (-3)
+
+/* One-time setup on `device`: derives the 130 Bulletproofs generators (PedersenGens::default,
+ * BulletproofGens::new party 0; replaces bp_gens_pair_bits, bulletproofs.rs:61-80), builds the
+ * fixed-base window tables and uploads them.  Idempotent.  Called implicitly by the prove calls. */
+int zkp_hip_init(int device);
+void zkp_hip_shutdown(void);
+/* Thread-local description of the last failure of a call made on this thread. */
+const char* zkp_hip_last_error(void);
+
+/* Replaces a loop of proof::range_proof::prove_range(value, min, max)
+ * (/root/reference/src/proof/range_proof.rs:10-27 -> BulletproofsBackend::prove_range_with_bounds_bits,
+ * /root/reference/src/backend/bulletproofs.rs:112-178) as issued by process_batch
+ * (/root/reference/src/advanced/batch.rs:123-131,264-266).
+ *   value,min,max : n host u64 each           seeds : 32*n host bytes or NULL
+ *   out           : n records of `stride` bytes (stride >= 1478); record i holds the version-2 Proof envelope
+ *   out_len[i]    : 1478 on success, 0 on failure      status[i] : per-item code (validation.rs:5-18)
+ * n_bits must be 64 (what prove_range uses, range_proof.rs:10-12). */
+int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* min, const uint64_t* max, uint32_t n_bits,
+                              const uint8_t* seeds, uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status);
+
+/* Same contract with every pointer a DEVICE pointer (inputs already resident in HBM, proofs left in HBM);
+ * `stream` is a hipStream_t (NULL = the library's own stream).  Asynchronous with respect to the host
+ * unless `any_failed` (host int, may be NULL) is requested, in which case the call synchronises the stream. */
+int zkp_hip_prove_range_batch_device(uint64_t n, const uint64_t* d_value, const uint64_t* d_min, const uint64_t* d_max, uint32_t n_bits,
+                                     const uint8_t* d_seeds, uint8_t* d_out, uint64_t stride, uint32_t* d_out_len, int32_t* d_status,
+                                     void* stream, int* any_failed);
+
+/* Kernel timing for the roofline line of bench.py: when enabled, every launch of the dominant kernel
+ * (fixed-base MSM) is bracketed by hipEvents on its own stream. */
+void zkp_hip_profile_enable(int on);
+/* Synchronises, then returns accumulated MSM kernel time (ms), launch count, and table-entry gathers
+ * (point additions) since the last reset. */
+int zkp_hip_profile_read(double* msm_ms, uint64_t* msm_launches, uint64_t* msm_point_adds, int reset);
+/* Tunables: windows of MSM work per workgroup chunk (default 128). Takes effect at the next zkp_hip_init. */
+void zkp_hip_set_window_budget(uint32_t budget);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

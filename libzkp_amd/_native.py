@@ -1,0 +1,59 @@
+"""ctypes binding of the C ABI in include/libzkp_hip.h (the same symbols the reference's Rust side would bind).
+
+There is deliberately no fallback: if the shared library is missing or no MI355X is present the calls raise.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libzkp_hip.so")
+
+RANGE_PROOF_BYTES = 1478
+# symbols declared in include/libzkp_hip.h (checked by tests/test_abi.py)
+EXPORTS = (
+    "zkp_hip_init", "zkp_hip_shutdown", "zkp_hip_last_error", "zkp_hip_prove_range_batch",
+    "zkp_hip_prove_range_batch_device", "zkp_hip_profile_enable", "zkp_hip_profile_read", "zkp_hip_set_window_budget",
+)
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                "libzkp_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                "libzkp_amd has no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        u64, u32, i32, vp = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p
+        L.zkp_hip_init.argtypes = [ctypes.c_int]
+        L.zkp_hip_init.restype = ctypes.c_int
+        L.zkp_hip_shutdown.restype = None
+        L.zkp_hip_last_error.restype = ctypes.c_char_p
+        L.zkp_hip_prove_range_batch.argtypes = [u64, vp, vp, vp, u32, vp, vp, u64, vp, vp]
+        L.zkp_hip_prove_range_batch.restype = ctypes.c_int
+        L.zkp_hip_prove_range_batch_device.argtypes = [u64, vp, vp, vp, u32, vp, vp, u64, vp, vp, vp, ctypes.POINTER(ctypes.c_int)]
+        L.zkp_hip_prove_range_batch_device.restype = ctypes.c_int
+        L.zkp_hip_profile_enable.argtypes = [ctypes.c_int]
+        L.zkp_hip_profile_enable.restype = None
+        L.zkp_hip_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.c_int]
+        L.zkp_hip_profile_read.restype = ctypes.c_int
+        L.zkp_hip_set_window_budget.argtypes = [u32]
+        L.zkp_hip_set_window_budget.restype = None
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().zkp_hip_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc < 0:
+        raise NativeError("%s failed (%d): %s" % (what, rc, last_error()))
+    return rc

@@ -1,0 +1,138 @@
+// Host-side setup shared by the HIP library and the test emulator: generator derivation
+// (PedersenGens::default / BulletproofGens::new party 0, /root/reference/src/backend/bulletproofs.rs:61-80,
+// SURVEY.md appendix A.2), fixed-base window tables, and the slot/chunk layouts of each MSM launch.
+// One-time initialisation work; no proof is ever computed on the host.
+#pragma once
+#include <vector>
+#include <utility>
+#include <cstring>
+#include "bp_steps.h"
+
+namespace zkp {
+
+inline void host_sponge(uint8_t* out, size_t outlen, const uint8_t* in, size_t inlen, size_t rate, uint8_t suffix) {
+    uint64_t a[25]; memset(a, 0, sizeof a);
+    uint8_t* b = reinterpret_cast<uint8_t*>(a);   // little-endian host
+    size_t pos = 0;
+    for (size_t i = 0; i < inlen; i++) { b[pos++] ^= in[i]; if (pos == rate) { keccak_f1600(a); pos = 0; } }
+    b[pos] ^= suffix; b[rate - 1] ^= 0x80;
+    keccak_f1600(a);
+    size_t done = 0;
+    while (done < outlen) {
+        size_t n = outlen - done < rate ? outlen - done : rate;
+        memcpy(out + done, b, n); done += n;
+        if (done < outlen) keccak_f1600(a);
+    }
+}
+
+inline ge host_from_uniform(const uint8_t b[64]) { uint32_t w[16]; memcpy(w, b, 64); return ge_from_uniform_words(w); }
+
+// ristretto basepoint = edwards25519 basepoint (x even), y = 4/5
+inline ge host_basepoint() {
+    const uint32_t yw[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u};
+    const uint32_t xw[8] = {0x8f25d51au, 0xc9562d60u, 0x9525a7b2u, 0x692cc760u, 0xfdd6dc5cu, 0xc0a4e231u, 0xcd6e53feu, 0x216936d3u};
+    ge p; p.X = fe_fromwords(xw); p.Y = fe_fromwords(yw); p.Z = fe_one(); p.T = fe_mul(p.X, p.Y);
+    return p;
+}
+
+// generators in table order: 0 = B, 1 = B_blinding, 2+i = G_i, 66+i = H_i
+inline void host_generators(ge out[NBASE]) {
+    out[BASE_B] = host_basepoint();
+    uint32_t enc[8]; ge_ristretto_encode(enc, out[BASE_B]);
+    uint8_t h[64]; host_sponge(h, 64, reinterpret_cast<uint8_t*>(enc), 32, 72, 0x06);   // SHA3-512
+    out[BASE_BB] = host_from_uniform(h);
+    for (int which = 0; which < 2; which++) {
+        uint8_t in[20]; memcpy(in, "GeneratorsChain", 15);
+        in[15] = which ? 'H' : 'G'; in[16] = in[17] = in[18] = in[19] = 0;
+        std::vector<uint8_t> stream(64 * BP_N);
+        host_sponge(stream.data(), stream.size(), in, 20, 136, 0x1F);                     // SHAKE256
+        for (uint32_t i = 0; i < BP_N; i++) out[(which ? BASE_H : BASE_G) + i] = host_from_uniform(stream.data() + 64 * i);
+    }
+}
+
+inline fe host_fe_invert(const fe& z) {   // z^(p-2) = (z^(2^252-3))^8 * z^3
+    fe t = fe_pow22523(z);
+    t = fe_sq(fe_sq(fe_sq(t)));
+    return fe_mul(t, fe_mul(fe_sq(z), z));
+}
+
+// table[(base*NWIN + w)*NENT + e] = (e+1) * 256^w * Base, affine niels, 30 canonical-limb words each
+inline void host_build_table_for_base(uint32_t* dst, const ge& base) {
+    std::vector<ge> pts(NWIN * NENT);
+    ge pw = base;
+    for (uint32_t w = 0; w < NWIN; w++) {
+        ge acc = pw;
+        for (uint32_t e = 0; e < NENT; e++) { pts[w * NENT + e] = acc; acc = ge_add(acc, pw); }
+        for (int k = 0; k < 8; k++) pw = ge_dbl(pw);
+    }
+    // batch inversion of Z
+    const size_t n = pts.size();
+    std::vector<fe> pre(n);
+    fe run = fe_one();
+    for (size_t i = 0; i < n; i++) { pre[i] = run; run = fe_mul(run, pts[i].Z); }
+    fe inv = host_fe_invert(run);
+    const fe d2 = fe_const_d2();
+    for (size_t i = n; i-- > 0;) {
+        const fe zi = fe_mul(inv, pre[i]);
+        inv = fe_mul(inv, pts[i].Z);
+        const fe x = fe_mul(pts[i].X, zi), y = fe_mul(pts[i].Y, zi);
+        uint32_t w8[8];
+        // store canonical (fully reduced) limbs so that device-side negation 2p - limb never underflows
+        fe_towords(w8, fe_add(y, x)); const fe ypx = fe_fromwords(w8);
+        fe_towords(w8, fe_sub(y, x)); const fe ymx = fe_fromwords(w8);
+        fe_towords(w8, fe_mul(fe_mul(x, y), d2)); const fe xy2d = fe_fromwords(w8);
+        uint32_t* q = dst + i * NIELS_W;
+        for (int k = 0; k < 10; k++) { q[k] = ypx.v[k]; q[10 + k] = ymx.v[k]; q[20 + k] = xy2d.v[k]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct MsmLayout {
+    std::vector<uint16_t> slot_base, chunk_begin, target_chunk_begin;
+    std::vector<uint8_t> slot_nwin;
+    uint32_t nslots() const { return (uint32_t)slot_base.size(); }
+    uint32_t nchunks() const { return (uint32_t)chunk_begin.size() - 1; }
+    uint32_t ntargets() const { return (uint32_t)target_chunk_begin.size() - 1; }
+};
+using SlotList = std::vector<std::pair<uint16_t, uint8_t>>;   // (base, nwin)
+
+// chunks never straddle targets; each chunk holds at most `win_budget` windows of work
+inline MsmLayout make_layout(const std::vector<SlotList>& targets, uint32_t win_budget) {
+    MsmLayout L;
+    L.chunk_begin.push_back(0); L.target_chunk_begin.push_back(0);
+    for (const auto& t : targets) {
+        uint32_t used = 0;
+        for (const auto& s : t) {
+            if (used > 0 && used + s.second > win_budget) { L.chunk_begin.push_back((uint16_t)L.slot_base.size()); used = 0; }
+            L.slot_base.push_back(s.first); L.slot_nwin.push_back(s.second); used += s.second;
+        }
+        L.chunk_begin.push_back((uint16_t)L.slot_base.size());
+        L.target_chunk_begin.push_back((uint16_t)(L.chunk_begin.size() - 1));
+    }
+    return L;
+}
+inline MsmLayout layout_phase1(uint32_t budget) {
+    SlotList v = {{BASE_B, 9}, {BASE_BB, 32}}, a = {{BASE_BB, 32}}, s = {{BASE_BB, 32}};
+    for (uint32_t i = 0; i < BP_N; i++) a.push_back({(uint16_t)(BASE_G + i), 1});
+    for (uint32_t i = 0; i < BP_N; i++) a.push_back({(uint16_t)(BASE_H + i), 1});
+    for (uint32_t i = 0; i < BP_N; i++) s.push_back({(uint16_t)(BASE_G + i), 32});
+    for (uint32_t i = 0; i < BP_N; i++) s.push_back({(uint16_t)(BASE_H + i), 32});
+    return make_layout({v, a, s}, budget);
+}
+inline MsmLayout layout_phase2(uint32_t budget) {
+    SlotList t = {{BASE_B, 32}, {BASE_BB, 32}};
+    return make_layout({t, t}, budget);
+}
+inline MsmLayout layout_round(uint32_t r, uint32_t budget) {
+    const uint32_t p = 5 - r, k = 1u << p;
+    auto idx = [&](uint32_t rank, uint32_t bit) { return ((rank >> p) << (p + 1)) | (bit << p) | (rank & (k - 1)); };
+    SlotList l = {{BASE_B, 32}}, rr = {{BASE_B, 32}};
+    for (uint32_t q = 0; q < 32; q++) l.push_back({(uint16_t)(BASE_G + idx(q, 1)), 32});
+    for (uint32_t q = 0; q < 32; q++) l.push_back({(uint16_t)(BASE_H + idx(q, 0)), 32});
+    for (uint32_t q = 0; q < 32; q++) rr.push_back({(uint16_t)(BASE_G + idx(q, 0)), 32});
+    for (uint32_t q = 0; q < 32; q++) rr.push_back({(uint16_t)(BASE_H + idx(q, 1)), 32});
+    return make_layout({l, rr}, budget);
+}
+inline MsmLayout layout_ctask(uint32_t budget) { return make_layout({SlotList{{BASE_B, 9}, {BASE_BB, 32}}}, budget); }
+
+}  // namespace zkp

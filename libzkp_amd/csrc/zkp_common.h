@@ -8,7 +8,7 @@
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
-#define ZKP_HD __host__ __device__ __forceinline__
+#define ZKP_HD __host__ __device__ __attribute__((always_inline))
 #define ZKP_HD_NOINLINE __host__ __device__ __noinline__
 #define ZKP_UNROLL _Pragma("unroll")
 #else

@@ -1,0 +1,457 @@
+// libzkp_hip: kernels + C ABI (include/libzkp_hip.h) of the MI355X Bulletproofs range prover.
+// gfx950 only.  One lane = one proof for every scalar/transcript step; the dominant kernel (k_msm)
+// streams fixed-base window sub-tables through LDS so that each table byte is fetched from L2 once per
+// 256 proofs and the per-lane table gathers hit LDS instead of HBM/L2.
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <atomic>
+#include <thread>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+#include <sys/random.h>
+#include "bp_layout.h"
+#include "../../include/libzkp_hip.h"
+
+using namespace zkp;
+
+// ================================================================================================ kernels
+static constexpr int TB = 256;   // threads per block for (i, job) grids
+static constexpr int TW = 64;    // one wave per block for per-job serial steps (STROBE image in LDS)
+
+__global__ void __launch_bounds__(TB) k_build_range(JobBuf J, uint32_t n, const uint64_t* value, const uint64_t* mn, const uint64_t* mx,
+                                                    uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
+    const uint32_t op = blockIdx.x * TB + threadIdx.x;
+    if (op < n) step_build_range(J, op, value, mn, mx, out, stride, out_len, status);
+}
+__global__ void __launch_bounds__(TB) k_ctask(CtView T) {
+    const uint32_t c = blockIdx.x * TB + threadIdx.x;
+    if (c < T.C) step_ctask(T, c);
+}
+__global__ void __launch_bounds__(TB) k_tape(BpView V) {
+    const uint32_t job = blockIdx.x * TB + threadIdx.x;
+    if (job < V.M) step_tape(V, blockIdx.y, job);
+}
+__global__ void __launch_bounds__(TB) k_poly(BpView V) {
+    const uint32_t job = blockIdx.x * TB + threadIdx.x;
+    if (job < V.M) step_poly(V, blockIdx.y, job);
+}
+__global__ void __launch_bounds__(TW) k_poly_sum(BpView V) {
+    const uint32_t job = blockIdx.x * TW + threadIdx.x;
+    if (job < V.M) step_poly_sum(V, job);
+}
+__global__ void __launch_bounds__(TB) k_lr_init(BpView V) {
+    const uint32_t job = blockIdx.x * TB + threadIdx.x;
+    if (job < V.M) step_lr_init(V, blockIdx.y, job);
+}
+__global__ void __launch_bounds__(TB) k_round_prep(BpView V, uint32_t r) {
+    const uint32_t job = blockIdx.x * TB + threadIdx.x;
+    if (job < V.M) step_round_prep(V, r, blockIdx.y, job);
+}
+__global__ void __launch_bounds__(TW) k_round_sum(BpView V, uint32_t r) {
+    const uint32_t job = blockIdx.x * TW + threadIdx.x;
+    if (job < V.M) step_round_sum(V, r, job);
+}
+// transcript steps: STROBE image of lane t at lds[i * TW + t] (conflict-free: consecutive lanes, consecutive banks)
+__global__ void __launch_bounds__(TW) k_transcript1(BpView V) {
+    __shared__ uint32_t lds[50 * TW];
+    const uint32_t job = blockIdx.x * TW + threadIdx.x;
+    Strobe s; s.base = lds + threadIdx.x; s.stride = TW; s.pos = 0; s.pos_begin = 0;
+    if (job < V.M) step_transcript1(V, job, s);
+}
+__global__ void __launch_bounds__(TW) k_transcript2(BpView V) {
+    __shared__ uint32_t lds[50 * TW];
+    const uint32_t job = blockIdx.x * TW + threadIdx.x;
+    Strobe s; s.base = lds + threadIdx.x; s.stride = TW; s.pos = 0; s.pos_begin = 0;
+    if (job < V.M) step_transcript2(V, job, s);
+}
+__global__ void __launch_bounds__(TW) k_transcript_round(BpView V, uint32_t r) {
+    __shared__ uint32_t lds[50 * TW];
+    const uint32_t job = blockIdx.x * TW + threadIdx.x;
+    Strobe s; s.base = lds + threadIdx.x; s.stride = TW; s.pos = 0; s.pos_begin = 0;
+    if (job < V.M) step_transcript_round(V, r, job, s);
+}
+__global__ void __launch_bounds__(TW) k_reduce(ReduceView R) {
+    const uint32_t row = blockIdx.x * TW + threadIdx.x;
+    if (row < R.rows) reduce_encode_thread(R, blockIdx.y, row);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fixed-base multiscalar multiplication, lane = proof.
+//   grid  : nchunks * ngroups workgroups of MSM_TB lanes; a workgroup owns one chunk of slots (same
+//           generators for all its lanes) and MSM_TB consecutive proofs.
+//   LDS   : the 15 KB sub-table (128 affine-niels multiples of 256^w * Base) of the current (slot, window),
+//           loaded with coalesced 16-byte loads (prefetched into registers during the previous window's
+//           point addition) and gathered per lane by its own signed digit.
+//   XCD   : workgroups that share a chunk (hence the same sub-tables) are mapped onto the same XCD so
+//           the sub-table stays in that XCD's 4 MB L2 (blocks b and b+8 share an XCD).
+static constexpr int MSM_TB = 256;
+static constexpr uint32_t SUBTAB_V4 = SUBTAB_W / 4;   // 960 x 16 bytes
+
+__global__ void __launch_bounds__(MSM_TB) k_msm(MsmView m, uint32_t ngroups, uint32_t nblocks) {
+    __shared__ uint4 lds4[SUBTAB_V4];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per_xcd = (nblocks + 7) / 8;
+    const uint32_t linear = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (linear >= nblocks) return;
+    const uint32_t chunk = linear / ngroups, group = linear % ngroups;
+    const uint32_t row = group * MSM_TB + tid;
+    const bool active = row < m.rows;
+    const uint32_t s1 = m.chunk_begin[chunk + 1];
+    uint32_t s = m.chunk_begin[chunk], w = 0;
+    ge acc = ge_identity();
+    uint4 pre[4];
+    auto prefetch = [&](uint32_t base, uint32_t win) {
+        const uint4* src = reinterpret_cast<const uint4*>(m.table + ((size_t)base * NWIN + win) * SUBTAB_W);
+        ZKP_UNROLL for (int q = 0; q < 4; q++) { const uint32_t idx = tid + q * MSM_TB; if (idx < SUBTAB_V4) pre[q] = src[idx]; }
+    };
+    if (s < s1) prefetch(m.slot_base[s], 0);
+    uint32_t dw = 0;
+    while (s < s1) {
+        const uint32_t nwin = m.slot_nwin[s];
+        __syncthreads();   // previous window's gathers are done
+        ZKP_UNROLL for (int q = 0; q < 4; q++) { const uint32_t idx = tid + q * MSM_TB; if (idx < SUBTAB_V4) lds4[idx] = pre[q]; }
+        __syncthreads();
+        uint32_t ns = s, nw = w + 1;
+        if (nw == nwin) { ns = s + 1; nw = 0; }
+        if (ns < s1) prefetch(m.slot_base[ns], nw);   // in flight during the point addition below
+        if ((w & 3u) == 0) dw = active ? m.digits[((size_t)s * 8 + (w >> 2)) * m.rows + row] : 0u;
+        const int32_t d = (int32_t)(int8_t)(dw >> (8 * (w & 3u)));
+        if (d != 0) acc = msm_accumulate_digit(acc, d, reinterpret_cast<const uint32_t*>(lds4));
+        s = ns; w = nw;
+    }
+    if (active) st_ge(m.partial, chunk, row, m.rows, acc);
+}
+
+// ================================================================================================ host
+namespace {
+
+thread_local std::string t_err;
+int fail(int code, const std::string& msg) { t_err = msg; return code; }
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) return fail(ZKP_HIP_E_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevLayout {
+    uint16_t *slot_base = nullptr, *chunk_begin = nullptr, *target_chunk_begin = nullptr;
+    uint8_t* slot_nwin = nullptr;
+    uint32_t nslots = 0, nchunks = 0, ntargets = 0;
+    uint64_t adds_per_row = 0;   // sum of nwin = point additions per proof in this launch
+};
+
+struct Ctx {
+    bool ready = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t* d_table = nullptr;
+    uint32_t budget = 128;
+    DevLayout p1, p2, rd[6], ct;
+    uint32_t max_chunks = 0;
+    // workspace
+    uint32_t capM = 0, capC = 0;
+    void* ws = nullptr;
+    // profiling
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double msm_ms = 0; uint64_t msm_launches = 0, msm_adds = 0;
+};
+Ctx g;
+std::mutex g_mu;
+uint32_t g_budget_request = 128;
+
+int upload_layout(DevLayout& D, const MsmLayout& L) {
+    D.nslots = L.nslots(); D.nchunks = L.nchunks(); D.ntargets = L.ntargets();
+    D.adds_per_row = 0; for (uint8_t x : L.slot_nwin) D.adds_per_row += x;
+    HIP_TRY(hipMalloc(&D.slot_base, L.slot_base.size() * 2));
+    HIP_TRY(hipMalloc(&D.chunk_begin, L.chunk_begin.size() * 2));
+    HIP_TRY(hipMalloc(&D.target_chunk_begin, L.target_chunk_begin.size() * 2));
+    HIP_TRY(hipMalloc(&D.slot_nwin, L.slot_nwin.size()));
+    HIP_TRY(hipMemcpy(D.slot_base, L.slot_base.data(), L.slot_base.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(D.chunk_begin, L.chunk_begin.data(), L.chunk_begin.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(D.target_chunk_begin, L.target_chunk_begin.data(), L.target_chunk_begin.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(D.slot_nwin, L.slot_nwin.data(), L.slot_nwin.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+void free_layout(DevLayout& D) {
+    (void)hipFree(D.slot_base); (void)hipFree(D.chunk_begin); (void)hipFree(D.target_chunk_begin); (void)hipFree(D.slot_nwin);
+    D = DevLayout();
+}
+
+int init_locked(int device) {
+    if (g.ready) {
+        if (device != g.device) return fail(ZKP_HIP_E_ARGUMENT, "zkp_hip_init: already initialised on another device");
+        return 0;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(ZKP_HIP_E_RUNTIME, "zkp_hip_init: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(ZKP_HIP_E_ARGUMENT, "zkp_hip_init: bad device index");
+    HIP_TRY(hipSetDevice(device));
+    g.device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    // generator tables (one-time, host)
+    const size_t words = (size_t)NBASE * NWIN * SUBTAB_W;
+    std::vector<uint32_t> tab(words);
+    ge gens[NBASE]; host_generators(gens);
+    {
+        std::atomic<int> next{0};
+        auto work = [&]() { for (int b; (b = next.fetch_add(1)) < (int)NBASE;) host_build_table_for_base(tab.data() + (size_t)b * NWIN * SUBTAB_W, gens[b]); };
+        unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 16) nt = 16;
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+    }
+    HIP_TRY(hipMalloc(&g.d_table, words * 4));
+    HIP_TRY(hipMemcpy(g.d_table, tab.data(), words * 4, hipMemcpyHostToDevice));
+    g.budget = g_budget_request ? g_budget_request : 128;
+    int rc;
+    if ((rc = upload_layout(g.p1, layout_phase1(g.budget)))) return rc;
+    if ((rc = upload_layout(g.p2, layout_phase2(g.budget)))) return rc;
+    for (uint32_t r = 0; r < 6; r++) if ((rc = upload_layout(g.rd[r], layout_round(r, g.budget)))) return rc;
+    if ((rc = upload_layout(g.ct, layout_ctask(g.budget)))) return rc;
+    g.max_chunks = g.p1.nchunks;
+    if (g.p2.nchunks > g.max_chunks) g.max_chunks = g.p2.nchunks;
+    for (uint32_t r = 0; r < 6; r++) if (g.rd[r].nchunks > g.max_chunks) g.max_chunks = g.rd[r].nchunks;
+    g.ready = true;
+    return 0;
+}
+
+// workspace carving ---------------------------------------------------------------------------------
+struct Ws {
+    JobBuf J; BpView V; CtView T;
+    uint32_t *partial, *ct_partial, *ct_enc;
+    uint64_t* ct_off;
+    int* flag;
+};
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// lays the workspace out for M jobs / C commitment tasks starting at base (nullptr = size query)
+size_t carve(uint8_t* base, uint32_t M, uint32_t C, uint32_t max_chunks, Ws* w) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { uint8_t* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
+    const size_t W = (size_t)8 * 4 * M;   // one scalar slot for all jobs
+    Ws t{};
+    t.J.v = (uint64_t*)take(8ull * M); t.J.seed_ix = (uint32_t*)take(4ull * M); t.J.proof_ix = (uint32_t*)take(4ull * M);
+    t.J.bl_plus = (int32_t*)take(4ull * M); t.J.bl_minus = (int32_t*)take(4ull * M); t.J.kind = (uint8_t*)take(M);
+    t.J.proof_off = (uint64_t*)take(8ull * M); t.J.commit_off = (uint64_t*)take(8ull * M);
+    t.J.ct_v = (uint64_t*)take(8ull * C); t.J.ct_seed_ix = (uint32_t*)take(4ull * C); t.J.ct_bl_ix = (uint32_t*)take(4ull * C); t.J.ct_off = (uint64_t*)take(8ull * C);
+    t.V.M = M; t.V.v = t.J.v; t.V.seed_ix = t.J.seed_ix; t.V.proof_ix = t.J.proof_ix; t.V.bl_plus = t.J.bl_plus; t.V.bl_minus = t.J.bl_minus;
+    t.V.kind = t.J.kind; t.V.proof_off = t.J.proof_off; t.V.commit_off = t.J.commit_off;
+    t.V.tape = (uint32_t*)take(W * TAPE_SLOTS); t.V.gamma = (uint32_t*)take(W);
+    t.V.d1 = (uint32_t*)take(W * P1_NSLOTS); t.V.d2 = (uint32_t*)take(W * P2_NSLOTS); t.V.dr = (uint32_t*)take(W * PR_NSLOTS);
+    t.V.ypow = (uint32_t*)take(W * 64); t.V.yinvpow = (uint32_t*)take(W * 64); t.V.r0 = (uint32_t*)take(W * 64); t.V.r1 = (uint32_t*)take(W * 64);
+    t.V.pp = (uint32_t*)take(W * 192); t.V.ab = (uint32_t*)take(W * 256); t.V.gh = (uint32_t*)take(W * 128);
+    t.V.scal = (uint32_t*)take(W * SC_NUM); t.V.tstate = (uint32_t*)take(4ull * 52 * M); t.V.enc = (uint32_t*)take(W * 3);
+    t.partial = (uint32_t*)take((size_t)max_chunks * GE_W * 4 * M);
+    t.T.C = C; t.T.v = t.J.ct_v; t.T.seed_ix = t.J.ct_seed_ix; t.T.bl_ix = t.J.ct_bl_ix;
+    t.T.digits = (uint32_t*)take((size_t)2 * 8 * 4 * C);
+    t.ct_partial = (uint32_t*)take((size_t)2 * GE_W * 4 * C);
+    t.ct_enc = (uint32_t*)take((size_t)8 * 4 * C);
+    t.ct_off = t.J.ct_off;
+    t.flag = (int*)take(256);
+    if (w) *w = t;
+    return off;
+}
+
+int ensure_workspace(uint32_t M, uint32_t C) {
+    if (M <= g.capM && C <= g.capC && g.ws) return 0;
+    if (g.ws) { HIP_TRY(hipFree(g.ws)); g.ws = nullptr; }
+    const uint32_t nm = M > g.capM ? M : g.capM, nc = C > g.capC ? C : g.capC;
+    const size_t bytes = carve(nullptr, nm, nc, g.max_chunks, nullptr);
+    HIP_TRY(hipMalloc(&g.ws, bytes));
+    g.capM = nm; g.capC = nc;
+    return 0;
+}
+
+int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32_t* partial, hipStream_t st) {
+    MsmView m; m.rows = rows; m.nslots = D.nslots; m.nchunks = D.nchunks; m.table = g.d_table; m.digits = digits;
+    m.slot_base = D.slot_base; m.slot_nwin = D.slot_nwin; m.chunk_begin = D.chunk_begin; m.partial = partial;
+    const uint32_t ngroups = (rows + MSM_TB - 1) / MSM_TB, nblocks = D.nchunks * ngroups;
+    const uint32_t grid = ((nblocks + 7) / 8) * 8;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g.profiling) {
+        if (g.ev_used == g.ev_pool.size()) {
+            hipEvent_t a, b; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b)); g.ev_pool.push_back({a, b});
+        }
+        e0 = g.ev_pool[g.ev_used].first; e1 = g.ev_pool[g.ev_used].second; g.ev_used++;
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    k_msm<<<grid, MSM_TB, 0, st>>>(m, ngroups, nblocks);
+    if (g.profiling) { HIP_TRY(hipEventRecord(e1, st)); g.msm_launches++; g.msm_adds += D.adds_per_row * rows; }
+    return 0;
+}
+int launch_reduce(const DevLayout& D, uint32_t rows, const uint32_t* partial, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
+    ReduceView R; R.rows = rows; R.ntargets = D.ntargets; R.partial = partial; R.target_chunk_begin = D.target_chunk_begin;
+    R.enc = enc; R.out_off = out_off; R.out = out;
+    k_reduce<<<dim3((rows + TW - 1) / TW, D.ntargets), TW, 0, st>>>(R);
+    return 0;
+}
+
+// the whole prover for M jobs + C commitment tasks already described in the workspace
+int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st) {
+    int rc;
+    const dim3 gj((M + TB - 1) / TB), gw((M + TW - 1) / TW);
+    if (C) {
+        k_ctask<<<(C + TB - 1) / TB, TB, 0, st>>>(w.T);
+        if ((rc = launch_msm(g.ct, C, w.T.digits, w.ct_partial, st))) return rc;
+        if ((rc = launch_reduce(g.ct, C, w.ct_partial, w.ct_enc, w.ct_off, w.V.out, st))) return rc;
+    }
+    k_tape<<<dim3(gj.x, TAPE_SLOTS + 1), TB, 0, st>>>(w.V);
+    if ((rc = launch_msm(g.p1, M, w.V.d1, w.partial, st))) return rc;
+    if ((rc = launch_reduce(g.p1, M, w.partial, w.V.enc, nullptr, nullptr, st))) return rc;
+    k_transcript1<<<gw, TW, 0, st>>>(w.V);
+    k_poly<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V);
+    k_poly_sum<<<gw, TW, 0, st>>>(w.V);
+    if ((rc = launch_msm(g.p2, M, w.V.d2, w.partial, st))) return rc;
+    if ((rc = launch_reduce(g.p2, M, w.partial, w.V.enc, nullptr, nullptr, st))) return rc;
+    k_transcript2<<<gw, TW, 0, st>>>(w.V);
+    k_lr_init<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V);
+    for (uint32_t r = 0; r < 6; r++) {
+        k_round_prep<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V, r);
+        k_round_sum<<<gw, TW, 0, st>>>(w.V, r);
+        if ((rc = launch_msm(g.rd[r], M, w.V.dr, w.partial, st))) return rc;
+        if ((rc = launch_reduce(g.rd[r], M, w.partial, w.V.enc, nullptr, nullptr, st))) return rc;
+        k_transcript_round<<<gw, TW, 0, st>>>(w.V, r);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+__global__ void k_any_failed(const int32_t* status, uint32_t n, int* flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && status[i] != 0) atomicOr(flag, 1);
+}
+
+int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_t* d_min, const uint64_t* d_max,
+                              const uint8_t* d_seeds, uint8_t* d_out, uint64_t stride, uint32_t* d_out_len, int32_t* d_status,
+                              hipStream_t st, int* any_failed) {
+    if (n == 0) { if (any_failed) *any_failed = 0; return 0; }
+    if (n > (1u << 30)) return fail(ZKP_HIP_E_ARGUMENT, "batch too large");
+    if (stride < RANGE_PROOF_BYTES) return fail(ZKP_HIP_E_ARGUMENT, "stride must be >= 1478");
+    const uint32_t C = (uint32_t)n, M = 2 * C;
+    int rc;
+    if ((rc = ensure_workspace(M, C))) return rc;
+    Ws w; carve((uint8_t*)g.ws, M, C, g.max_chunks, &w);
+    w.V.seeds = reinterpret_cast<const uint32_t*>(d_seeds); w.T.seeds = w.V.seeds; w.V.out = d_out;
+    k_build_range<<<(C + TB - 1) / TB, TB, 0, st>>>(w.J, C, d_value, d_min, d_max, d_out, stride, d_out_len, d_status);
+    if ((rc = run_pipeline(w, M, C, st))) return rc;
+    if (any_failed) {
+        HIP_TRY(hipMemsetAsync(w.flag, 0, sizeof(int), st));
+        k_any_failed<<<(C + TB - 1) / TB, TB, 0, st>>>(d_status, C, w.flag);
+        HIP_TRY(hipMemcpyAsync(any_failed, w.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+const char* zkp_hip_last_error(void) { return t_err.c_str(); }
+void zkp_hip_set_window_budget(uint32_t budget) { g_budget_request = budget; }
+
+int zkp_hip_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return init_locked(device);
+}
+
+void zkp_hip_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.ready) return;
+    (void)hipSetDevice(g.device);
+    (void)hipStreamSynchronize(g.stream);
+    (void)hipFree(g.ws); (void)hipFree(g.d_table);
+    free_layout(g.p1); free_layout(g.p2); free_layout(g.ct);
+    for (auto& d : g.rd) free_layout(d);
+    for (auto& e : g.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    (void)hipStreamDestroy(g.stream);
+    g = Ctx();
+}
+
+void zkp_hip_profile_enable(int on) { std::lock_guard<std::mutex> lk(g_mu); g.profiling = on != 0; }
+
+int zkp_hip_profile_read(double* msm_ms, uint64_t* msm_launches, uint64_t* msm_point_adds, int reset) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.ready) return fail(ZKP_HIP_E_ARGUMENT, "not initialised");
+    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (size_t i = 0; i < g.ev_used; i++) {
+        float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, g.ev_pool[i].first, g.ev_pool[i].second)); g.msm_ms += ms;
+    }
+    g.ev_used = 0;
+    if (msm_ms) *msm_ms = g.msm_ms;
+    if (msm_launches) *msm_launches = g.msm_launches;
+    if (msm_point_adds) *msm_point_adds = g.msm_adds;
+    if (reset) { g.msm_ms = 0; g.msm_launches = 0; g.msm_adds = 0; }
+    return 0;
+}
+
+int zkp_hip_prove_range_batch_device(uint64_t n, const uint64_t* d_value, const uint64_t* d_min, const uint64_t* d_max, uint32_t n_bits,
+                                     const uint8_t* d_seeds, uint8_t* d_out, uint64_t stride, uint32_t* d_out_len, int32_t* d_status,
+                                     void* stream, int* any_failed) {
+    if (n_bits != 64) return fail(ZKP_HIP_E_UNSUPPORTED, "only n_bits = 64 is implemented (what prove_range uses)");
+    if (!d_seeds) return fail(ZKP_HIP_E_ARGUMENT, "device entry point needs seeds");
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = init_locked(g.ready ? g.device : 0);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(g.device));
+    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    rc = prove_range_device_locked(n, d_value, d_min, d_max, d_seeds, d_out, stride, d_out_len, d_status, st, any_failed);
+    if (rc) return rc;
+    return (any_failed && *any_failed) ? 1 : 0;
+}
+
+int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* min, const uint64_t* max, uint32_t n_bits,
+                              const uint8_t* seeds, uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
+    if (n_bits != 64) return fail(ZKP_HIP_E_UNSUPPORTED, "only n_bits = 64 is implemented (what prove_range uses)");
+    if (n == 0) return 0;
+    if (!value || !min || !max || !out || !out_len || !status) return fail(ZKP_HIP_E_ARGUMENT, "null pointer argument");
+    if (stride < RANGE_PROOF_BYTES) return fail(ZKP_HIP_E_ARGUMENT, "stride must be >= 1478");
+    std::vector<uint8_t> fresh;
+    if (!seeds) {   // reference behaviour: fresh OS randomness per proof (bulletproofs.rs:82-87)
+        fresh.resize(32 * n);
+        size_t got = 0;
+        while (got < fresh.size()) {
+            ssize_t r = getrandom(fresh.data() + got, fresh.size() - got, 0);
+            if (r <= 0) return fail(ZKP_HIP_E_RUNTIME, "getrandom failed");
+            got += (size_t)r;
+        }
+        seeds = fresh.data();
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = init_locked(g.ready ? g.device : 0);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(g.device));
+    hipStream_t st = g.stream;
+    uint64_t *d_in = nullptr; uint8_t *d_seeds = nullptr, *d_out = nullptr; uint32_t* d_len = nullptr; int32_t* d_status = nullptr;
+    HIP_TRY(hipMalloc(&d_in, 24 * n)); HIP_TRY(hipMalloc(&d_seeds, 32 * n)); HIP_TRY(hipMalloc(&d_out, stride * n));
+    HIP_TRY(hipMalloc(&d_len, 4 * n)); HIP_TRY(hipMalloc(&d_status, 4 * n));
+    HIP_TRY(hipMemcpyAsync(d_in, value, 8 * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_in + n, min, 8 * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_in + 2 * n, max, 8 * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_seeds, seeds, 32 * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_out, 0, stride * n, st));
+    int any = 0;
+    rc = prove_range_device_locked(n, d_in, d_in + n, d_in + 2 * n, d_seeds, d_out, stride, d_len, d_status, st, &any);
+    if (rc == 0) {
+        HIP_TRY(hipMemcpyAsync(out, d_out, stride * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_len, d_len, 4 * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(status, d_status, 4 * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        // a failed item leaves no proof bytes behind (reference returns Err, never a partial Vec)
+        for (uint64_t i = 0; i < n; i++) if (status[i] != 0) memset(out + i * stride, 0, stride);
+    }
+    (void)hipFree(d_in); (void)hipFree(d_seeds); (void)hipFree(d_out); (void)hipFree(d_len); (void)hipFree(d_status);
+    if (rc) return rc;
+    return any ? 1 : 0;
+}
+
+}  // extern "C"

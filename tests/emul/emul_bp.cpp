@@ -1,0 +1,84 @@
+// TEST INFRASTRUCTURE: runs the per-thread step functions of the HIP prover on the CPU (plain loops in
+// place of kernel launches) so the no-GPU test tier can compare them with the oracle byte for byte.
+// Not part of the product library; the product has no host proving path.
+#include "../../libzkp_amd/csrc/bp_layout.h"
+#include <vector>
+#include <cstdlib>
+using namespace zkp;
+
+static std::vector<uint32_t> g_table;
+static void ensure_table() {
+    if (!g_table.empty()) return;
+    g_table.resize((size_t)NBASE * NWIN * SUBTAB_W);
+    ge gens[NBASE]; host_generators(gens);
+    for (uint32_t b = 0; b < NBASE; b++) host_build_table_for_base(g_table.data() + (size_t)b * NWIN * SUBTAB_W, gens[b]);
+}
+
+struct DevLayout { MsmLayout L; };
+
+static void run_msm(const MsmLayout& L, uint32_t rows, const uint32_t* digits, std::vector<uint32_t>& partial) {
+    MsmView m; m.rows = rows; m.nslots = L.nslots(); m.nchunks = L.nchunks(); m.table = g_table.data(); m.digits = digits;
+    m.slot_base = L.slot_base.data(); m.slot_nwin = L.slot_nwin.data(); m.chunk_begin = L.chunk_begin.data();
+    partial.assign((size_t)L.nchunks() * GE_W * rows, 0); m.partial = partial.data();
+    for (uint32_t c = 0; c < L.nchunks(); c++) for (uint32_t row = 0; row < rows; row++) msm_chunk_ref(m, c, row);
+}
+static void run_reduce(const MsmLayout& L, uint32_t rows, const std::vector<uint32_t>& partial, uint32_t* enc, const uint64_t* out_off, uint8_t* out) {
+    ReduceView r; r.rows = rows; r.ntargets = L.ntargets(); r.partial = partial.data(); r.target_chunk_begin = L.target_chunk_begin.data();
+    r.enc = enc; r.out_off = out_off; r.out = out;
+    for (uint32_t t = 0; t < L.ntargets(); t++) for (uint32_t row = 0; row < rows; row++) reduce_encode_thread(r, t, row);
+}
+
+extern "C" {
+void emul_generator(uint32_t idx, uint32_t enc[8]) { ge g[NBASE]; host_generators(g); ge_ristretto_encode(enc, g[idx]); }
+
+// same contract as zkp_hip_prove_range_batch (include/libzkp_hip.h) with n_bits = 64
+int emul_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* mn, const uint64_t* mx, const uint8_t* seeds,
+                           uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status, uint32_t win_budget) {
+    ensure_table();
+    const uint32_t M = (uint32_t)(2 * n), C = (uint32_t)n;
+    std::vector<uint64_t> v(M), poff(M), coff(M), ctv(C), ctoff(C);
+    std::vector<uint32_t> six(M), pix(M), ctsix(C), ctbl(C);
+    std::vector<int32_t> blp(M), blm(M);
+    std::vector<uint8_t> kind(M);
+    JobBuf J{v.data(), six.data(), pix.data(), blp.data(), blm.data(), kind.data(), poff.data(), coff.data(), ctv.data(), ctsix.data(), ctbl.data(), ctoff.data()};
+    for (uint32_t op = 0; op < n; op++) step_build_range(J, op, value, mn, mx, out, stride, out_len, status);
+    std::vector<uint32_t> seedw(8 * n); memcpy(seedw.data(), seeds, 32 * n);
+    auto words = [&](size_t k) { return std::vector<uint32_t>(k * 8 * M, 0xDEADBEEFu); };
+    auto tape = words(TAPE_SLOTS), gamma = words(1), d1 = words(P1_NSLOTS), d2 = words(P2_NSLOTS), dr = words(PR_NSLOTS), ypow = words(64), yinv = words(64),
+         r0 = words(64), r1 = words(64), pp = words(192), ab = words(256), gh = words(128), scal = words(SC_NUM), enc = words(3);
+    std::vector<uint32_t> tstate((size_t)52 * M);
+    BpView V; V.M = M; V.v = v.data(); V.seed_ix = six.data(); V.proof_ix = pix.data(); V.bl_plus = blp.data(); V.bl_minus = blm.data(); V.kind = kind.data();
+    V.seeds = seedw.data(); V.proof_off = poff.data(); V.commit_off = coff.data(); V.out = out;
+    V.tape = tape.data(); V.gamma = gamma.data(); V.d1 = d1.data(); V.d2 = d2.data(); V.dr = dr.data(); V.ypow = ypow.data(); V.yinvpow = yinv.data();
+    V.r0 = r0.data(); V.r1 = r1.data(); V.pp = pp.data(); V.ab = ab.data(); V.gh = gh.data(); V.scal = scal.data(); V.tstate = tstate.data(); V.enc = enc.data();
+    std::vector<uint32_t> partial;
+    uint32_t st[50]; Strobe s; s.base = st; s.stride = 1;
+
+    // commitment tasks
+    std::vector<uint32_t> ctd((size_t)2 * 8 * C), ctenc((size_t)8 * C);
+    CtView T{C, ctv.data(), ctsix.data(), ctbl.data(), seedw.data(), ctd.data()};
+    for (uint32_t c = 0; c < C; c++) step_ctask(T, c);
+    MsmLayout Lc = layout_ctask(win_budget);
+    run_msm(Lc, C, ctd.data(), partial); run_reduce(Lc, C, partial, ctenc.data(), ctoff.data(), out);
+
+    for (uint32_t slot = 0; slot <= TAPE_SLOTS; slot++) for (uint32_t j = 0; j < M; j++) step_tape(V, slot, j);
+    MsmLayout L1 = layout_phase1(win_budget);
+    run_msm(L1, M, V.d1, partial); run_reduce(L1, M, partial, V.enc, nullptr, nullptr);
+    for (uint32_t j = 0; j < M; j++) step_transcript1(V, j, s);
+    for (uint32_t i = 0; i < BP_N; i++) for (uint32_t j = 0; j < M; j++) step_poly(V, i, j);
+    for (uint32_t j = 0; j < M; j++) step_poly_sum(V, j);
+    MsmLayout L2 = layout_phase2(win_budget);
+    run_msm(L2, M, V.d2, partial); run_reduce(L2, M, partial, V.enc, nullptr, nullptr);
+    for (uint32_t j = 0; j < M; j++) step_transcript2(V, j, s);
+    for (uint32_t i = 0; i < BP_N; i++) for (uint32_t j = 0; j < M; j++) step_lr_init(V, i, j);
+    for (uint32_t r = 0; r < 6; r++) {
+        for (uint32_t i = 0; i < BP_N; i++) for (uint32_t j = 0; j < M; j++) step_round_prep(V, r, i, j);
+        for (uint32_t j = 0; j < M; j++) step_round_sum(V, r, j);
+        MsmLayout Lr = layout_round(r, win_budget);
+        run_msm(Lr, M, V.dr, partial); run_reduce(Lr, M, partial, V.enc, nullptr, nullptr);
+        for (uint32_t j = 0; j < M; j++) step_transcript_round(V, r, j, s);
+    }
+    int fail = 0; for (uint32_t op = 0; op < n; op++) fail |= status[op] != 0;
+    return fail;
+}
+}
