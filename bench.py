@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: process_batch of 4096 prove_range(v, 0, 2^32) per GPU (BASELINE.json configs[1]).
+
+One "step" = one pass of the HIP range prover over one batch of 4096 synthetic ops whose inputs (values,
+bounds, per-proof seeds) are already resident in HBM; proofs are left in HBM.  Multi-GPU = one process per
+GPU, each proving its own 4096-op batch (independent ops, no data-path collective; weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel (fixed-base MSM) against the HBM roof, as the contract asks, plus
+  roofline_valu the same kernel against the VALU integer roof that actually binds it
+  cpu_baseline  oracle/c (a scalar C port of upstream's algorithm, OpenMP over proofs) on a bounded sample.
+"""
+import argparse
+import ctypes
+import hashlib
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 4096
+PROOF_BYTES = 1478
+ALGO_BYTES_PER_PROOF = 24 + 32 + 1478   # params + seed in, proof out
+HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md
+FE_MUL_PEAK_G = 257.0                    # measured: tools/fe_microbench.hip variant B on MI355X (G field-mul/s)
+FE_MUL_PER_POINT_ADD = 7
+
+
+def make_workload(n, seed):
+    """C2 of BASELINE.md: value ~ U[0, 2^32], min = 0, max = 2^32; per-proof seed = SHA-256(seed || i)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    v = rng.integers(0, 2**32, n, dtype=np.uint64, endpoint=True)
+    mn = np.zeros(n, dtype=np.uint64)
+    mx = np.full(n, 2**32, dtype=np.uint64)
+    seeds = np.frombuffer(b"".join(hashlib.sha256(seed.to_bytes(8, "little") + i.to_bytes(8, "little")).digest() for i in range(n)), dtype=np.uint8).copy()
+    return v, mn, mx, seeds
+
+
+def cpu_baseline(sample, threads):
+    import numpy as np
+    path = os.path.join(ROOT, "oracle", "_build", "libzkp_oracle.so")
+    orc = ctypes.CDLL(path)
+    orc.zkp_oracle_init()
+    v, mn, mx, seeds = make_workload(sample, 1)
+    out = np.zeros((sample, PROOF_BYTES), dtype=np.uint8)
+    lens = np.zeros(sample, dtype=np.uint32)
+    st = np.zeros(sample, dtype=np.int32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    u64 = ctypes.c_uint64
+    # warm-up (thread pool, page faults)
+    orc.zkp_oracle_prove_range_batch(u64(min(sample, threads)), P(v), P(mn), P(mx), 64, P(seeds), P(out), u64(PROOF_BYTES), P(lens), P(st), threads)
+    t0 = time.perf_counter()
+    rc = orc.zkp_oracle_prove_range_batch(u64(sample), P(v), P(mn), P(mx), 64, P(seeds), P(out), u64(PROOF_BYTES), P(lens), P(st), threads)
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    return {"value": sample / dt, "unit": "proofs/s", "cores": threads, "kind": "port",
+            "sample": "first %d ops of the same 4096-op workload, oracle/c (scalar C restatement of upstream's Straus + "
+                      "generator-folding prover), OpenMP %d threads, %.1f s wall" % (sample, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--window-budget", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP prover has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from libzkp_amd import _native
+    L = _native.lib()
+    if args.window_budget:
+        L.zkp_hip_set_window_budget(args.window_budget)
+    _native.check(L.zkp_hip_init(local_rank), "zkp_hip_init")
+
+    n = args.batch
+    v, mn, mx, seeds = make_workload(n, 1 + rank)
+    dev = torch.device("cuda", local_rank)
+    d_v = torch.from_numpy(v.view(np.int64)).to(dev)
+    d_mn = torch.from_numpy(mn.view(np.int64)).to(dev)
+    d_mx = torch.from_numpy(mx.view(np.int64)).to(dev)
+    d_seeds = torch.from_numpy(seeds).to(dev)
+    d_out = torch.zeros((n, PROOF_BYTES), dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        rc = L.zkp_hip_prove_range_batch_device(n, d_v.data_ptr(), d_mn.data_ptr(), d_mx.data_ptr(), 64, d_seeds.data_ptr(),
+                                                d_out.data_ptr(), PROOF_BYTES, d_len.data_ptr(), d_st.data_ptr(),
+                                                ctypes.c_void_p(stream.cuda_stream), None)
+        _native.check(rc, "zkp_hip_prove_range_batch_device")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    L.zkp_hip_profile_enable(1)
+    L.zkp_hip_profile_read(None, None, None, 1)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record(stream)
+    for k in range(args.steps):
+        step()
+        evs[k + 1].record(stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    msm_ms, msm_launches, msm_adds = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+    L.zkp_hip_profile_read(ctypes.byref(msm_ms), ctypes.byref(msm_launches), ctypes.byref(msm_adds), 1)
+    L.zkp_hip_profile_enable(0)
+    step_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps)]
+
+    # correctness guard inside the bench: every op succeeded
+    assert int(d_st.abs().sum().item()) == 0 and int((d_len != PROOF_BYTES).sum().item()) == 0
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total = world * args.steps * n
+        avg_launch_ms = msm_ms.value / max(1, msm_launches.value)
+        # algorithmic bytes one MSM launch must move: SURVEY 8(d) per-proof bytes x proofs the launch processes
+        algo_bytes_launch = ALGO_BYTES_PER_PROOF * n
+        achieved_gbs = algo_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+        fe_mul_rate_g = msm_adds.value * FE_MUL_PER_POINT_ADD / (msm_ms.value * 1e-3) / 1e9 if msm_ms.value > 0 else 0.0
+        res = {
+            "metric": "proofs/sec (whole node), 4096-op prove_range(v,0,2^32) batch per GPU",
+            "value": total / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 limbs (25.5-bit radix GF(2^255-19), 8x32 Montgomery mod l)", "data": "synthetic",
+            "config": {"workload": "process_batch of %d prove_range(v, 0, 2^32), n_bits=64, seed 1 (BASELINE.md C2)" % n,
+                       "ops_per_gpu_per_step": n, "proof_bytes": PROOF_BYTES, "sharding": "independent ops per rank, no collective"},
+            "ms_per_proof_p50": statistics.median(step_ms) / n,
+            "ms_per_batch_p50": statistics.median(step_ms),
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None, "kernel": "k_msm",
+                         "avg_launch_ms": avg_launch_ms, "launches": msm_launches.value,
+                         "algorithmic_bytes_per_launch": algo_bytes_launch,
+                         "note": "integer-ALU-bound kernel (SURVEY 8d): see roofline_valu"},
+            "roofline_valu": {"bound": "valu-int", "achieved": fe_mul_rate_g, "peak": FE_MUL_PEAK_G, "unit": "G field-mul/s",
+                              "frac": fe_mul_rate_g / FE_MUL_PEAK_G, "kernel": "k_msm",
+                              "msm_share_of_step": msm_ms.value / (dt * 1e3) if world == 1 else None},
+        }
+        if not args.no_cpu_baseline:
+            threads = min(len(os.sched_getaffinity(0)), 32)
+            res["cpu_baseline"] = cpu_baseline(args.cpu_sample, threads)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,20 @@
+"""libzkp_amd -- MI355X-native proving backend for libzkp's Bulletproofs hot path.
+
+Python surface mirroring the names of the reference's PyO3 module (/root/reference/src/python_api.rs:110-164)
+for the path in scope: range proofs and the batch driver.  Everything is computed by the
+HIP library behind the C ABI of include/libzkp_hip.h; there is no CPU fallback.
+"""
+from .api import (  # noqa: F401
+    prove_range, prove_range_batch, create_proof_batch, batch_add_range_proof, batch_add_equality_proof,
+    batch_add_threshold_proof, batch_add_membership_proof, batch_add_improvement_proof, batch_add_consistency_proof,
+    process_batch, get_batch_status, clear_batch, benchmark_proof_generation, benchmark_proof_generation_numeric,
+    ZkpBackendError,
+)
+from ._native import NativeError  # noqa: F401
+
+__all__ = [
+    "prove_range", "prove_range_batch", "create_proof_batch", "batch_add_range_proof", "batch_add_equality_proof",
+    "batch_add_threshold_proof", "batch_add_membership_proof", "batch_add_improvement_proof", "batch_add_consistency_proof",
+    "process_batch", "get_batch_status", "clear_batch", "benchmark_proof_generation", "benchmark_proof_generation_numeric",
+    "NativeError", "ZkpBackendError",
+]

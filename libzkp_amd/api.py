@@ -1,0 +1,216 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Same names, argument meaning and error behaviour as the reference:
+  prove_range                 /root/reference/src/proof/range_proof.rs:10-27   (validation.rs:5-18 messages)
+  create_proof_batch .. process_batch, get_batch_status, clear_batch
+                              /root/reference/src/advanced/batch.rs:35-175,262-283
+  benchmark_proof_generation  /root/reference/src/advanced/mod.rs:83-172,204-215
+Error mapping follows /root/reference/src/utils/error_handling.rs:39-50: InvalidInput -> ValueError(msg);
+everything else -> RuntimeError("<Display prefix>: msg").
+"""
+import ctypes
+import secrets
+import threading
+import time
+
+import numpy as np
+
+from . import _native
+
+U64_MAX = 2**64 - 1
+
+
+class ZkpBackendError(RuntimeError):
+    pass
+
+
+def _check_u64(name, x):
+    if not isinstance(x, (int, np.integer)) or isinstance(x, bool) or x < 0 or x > U64_MAX:
+        raise OverflowError("%s out of range for u64" % name)
+    return int(x)
+
+
+def validate_range_params(value, mn, mx):
+    """validation.rs:5-18."""
+    if mn > mx:
+        raise ValueError("min cannot be greater than max")
+    if value < mn or value > mx:
+        raise ValueError("value %d is not in range [%d, %d]" % (value, mn, mx))
+
+
+def _P(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def prove_range_batch(values, mins, maxs, seeds=None, device=None):
+    """Batched prove_range: returns a list of proof bytes (one 1478-byte envelope per op).
+
+    Raises ValueError (reference message) if any op is invalid -- like process_batch, one failure fails the call.
+    `seeds` (n x 32 bytes) pins the randomness tape; None draws fresh OS randomness like the reference.
+    """
+    n = len(values)
+    v = np.array([_check_u64("value", x) for x in values], dtype=np.uint64)
+    mn = np.array([_check_u64("min", x) for x in mins], dtype=np.uint64)
+    mx = np.array([_check_u64("max", x) for x in maxs], dtype=np.uint64)
+    if not (len(mn) == n and len(mx) == n):
+        raise ValueError("values, mins, maxs must have equal length")
+    for i in range(n):
+        validate_range_params(int(v[i]), int(mn[i]), int(mx[i]))
+    if n == 0:
+        return []
+    L = _native.lib()
+    if device is not None:
+        _native.check(L.zkp_hip_init(int(device)), "zkp_hip_init")
+    sp = None
+    if seeds is not None:
+        s = np.frombuffer(bytes(seeds), dtype=np.uint8) if not isinstance(seeds, np.ndarray) else seeds.astype(np.uint8).ravel()
+        if s.size != 32 * n:
+            raise ValueError("seeds must hold 32 bytes per op")
+        s = np.ascontiguousarray(s)
+        sp = _P(s)
+    out = np.zeros((n, _native.RANGE_PROOF_BYTES), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint32)
+    st = np.zeros(n, dtype=np.int32)
+    rc = L.zkp_hip_prove_range_batch(n, _P(v), _P(mn), _P(mx), 64, sp, _P(out), _native.RANGE_PROOF_BYTES, _P(lens), _P(st))
+    if rc < 0:
+        raise ZkpBackendError("Backend error: %s" % _native.last_error())
+    if rc > 0:
+        bad = int(np.nonzero(st)[0][0])
+        raise ZkpBackendError("Backend error: range proof generation failed for op %d (status %d)" % (bad, int(st[bad])))
+    return [out[i, : lens[i]].tobytes() for i in range(n)]
+
+
+def prove_range(value, min, max):  # noqa: A002  (reference argument names)
+    value, mn, mx = _check_u64("value", value), _check_u64("min", min), _check_u64("max", max)
+    validate_range_params(value, mn, mx)
+    return prove_range_batch([value], [mn], [mx])[0]
+
+
+# ---------------------------------------------------------------- batch registry (batch.rs:18-175)
+_registry = {}
+_registry_lock = threading.Lock()
+_OUT_OF_SCOPE = ("%s proofs are produced by the %s backend, which this round's HIP path does not cover yet "
+                 "(SURVEY.md section 8: Bulletproofs range path first)")
+
+
+def create_proof_batch():
+    with _registry_lock:
+        while True:
+            bid = secrets.randbits(64)
+            if bid != 0 and bid not in _registry:
+                _registry[bid] = []
+                return bid
+
+
+def _with_batch(batch_id, op):
+    with _registry_lock:
+        if batch_id not in _registry:
+            raise ValueError("Invalid batch ID: %d" % batch_id)
+        _registry[batch_id].append(op)
+
+
+def batch_add_range_proof(batch_id, value, min, max):  # noqa: A002
+    value, mn, mx = _check_u64("value", value), _check_u64("min", min), _check_u64("max", max)
+    validate_range_params(value, mn, mx)
+    _with_batch(batch_id, ("range", value, mn, mx))
+
+
+def batch_add_equality_proof(batch_id, val1, val2):
+    if val1 != val2:
+        raise ValueError("values are not equal")
+    _with_batch(batch_id, ("equality", val1, val2))
+
+
+def batch_add_threshold_proof(batch_id, values, threshold):
+    values = [_check_u64("value", x) for x in values]
+    if not values:
+        raise ValueError("values cannot be empty")
+    total = sum(values)
+    if total > U64_MAX:
+        raise ValueError("integer overflow in sum calculation")
+    if total < threshold:
+        raise ValueError("sum %d is less than threshold %d" % (total, threshold))
+    _with_batch(batch_id, ("threshold", tuple(values), threshold))
+
+
+def batch_add_membership_proof(batch_id, value, set):  # noqa: A002
+    if not set:
+        raise ValueError("set cannot be empty")
+    if value not in set:
+        raise ValueError("value %d is not in the provided set" % value)
+    _with_batch(batch_id, ("membership", value, tuple(set)))
+
+
+def batch_add_improvement_proof(batch_id, old, new):
+    if new <= old:
+        raise ValueError("new value must be greater than old value")
+    _with_batch(batch_id, ("improvement", old, new))
+
+
+def batch_add_consistency_proof(batch_id, data):
+    data = [_check_u64("value", x) for x in data]
+    if not data:
+        raise ValueError("data cannot be empty")
+    if any(a > b for a, b in zip(data, data[1:])):
+        raise ValueError("data is not monotonic non-decreasing")
+    _with_batch(batch_id, ("consistency", tuple(data)))
+
+
+def process_batch(batch_id, seeds=None):
+    """batch.rs:110-140: consumes the batch (even if proving fails), returns proofs in insertion order."""
+    with _registry_lock:
+        if batch_id not in _registry:
+            raise ValueError("Invalid batch ID: %d" % batch_id)
+        ops = _registry.pop(batch_id)
+    for op in ops:
+        if op[0] != "range":
+            backend = {"equality": "Groth16", "membership": "Groth16", "improvement": "STARK"}.get(op[0], "Bulletproofs")
+            raise NotImplementedError(_OUT_OF_SCOPE % (op[0], backend))
+    return prove_range_batch([o[1] for o in ops], [o[2] for o in ops], [o[3] for o in ops], seeds=seeds)
+
+
+def get_batch_status(batch_id):
+    with _registry_lock:
+        if batch_id not in _registry:
+            raise ValueError("Invalid batch ID: %d" % batch_id)
+        ops = list(_registry[batch_id])
+    out = {"total_operations": len(ops)}
+    for key, name in (("range_proofs", "range"), ("equality_proofs", "equality"), ("threshold_proofs", "threshold"),
+                      ("membership_proofs", "membership"), ("improvement_proofs", "improvement"), ("consistency_proofs", "consistency")):
+        out[key] = sum(1 for o in ops if o[0] == name)
+    return out
+
+
+def clear_batch(batch_id):
+    with _registry_lock:
+        _registry.pop(batch_id, None)
+
+
+# ---------------------------------------------------------------- benchmark harness (advanced/mod.rs:83-172)
+def benchmark_proof_generation_numeric(proof_type, iterations):
+    if proof_type != "range":
+        if proof_type in ("equality", "threshold", "membership", "improvement", "consistency"):
+            raise NotImplementedError(_OUT_OF_SCOPE % (proof_type, "corresponding"))
+        raise ValueError("unsupported proof type: %s" % proof_type)
+    times = []
+    for _ in range(iterations):
+        t0 = time.perf_counter()
+        prove_range(50, 0, 100)                       # mod.rs:94
+        times.append((time.perf_counter() - t0) * 1e3)
+    if not times:
+        raise ValueError("no successful proof generations")
+    total = sum(times)
+    avg = total / len(times)
+    var = sum((x - avg) ** 2 for x in times) / len(times)
+    return {
+        "iterations": float(iterations), "successful_iterations": float(len(times)), "success_rate": 100.0,
+        "total_time_ms": total, "avg_time_ms": avg, "min_time_ms": min(times), "max_time_ms": max(times),
+        "std_dev_ms": var ** 0.5, "proofs_per_second": len(times) / (total / 1e3), "throughput_ms_per_proof": total / len(times),
+    }
+
+
+def benchmark_proof_generation(proof_type, iterations):
+    """mod.rs:204-215: the Python variant stringifies every value and adds proof_type."""
+    res = {k: repr(float(v)) for k, v in benchmark_proof_generation_numeric(proof_type, iterations).items()}
+    res["proof_type"] = proof_type
+    return res

@@ -1,0 +1,55 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the sharded batch driver with the oracle standing in as the
+prover (checks partitioning, order preservation and the gather; the GPU prover itself is covered by -m gpu)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+from libzkp_amd.sharding import shard_bounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 8, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = textwrap.dedent("""
+    import ctypes, os, sys
+    import numpy as np
+    sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import torch.distributed as dist
+    from libzkp_amd.sharding import process_range_batch_sharded
+    from util import oracle_prove, workload
+    import __graft_entry__ as ge
+    orc = ctypes.CDLL(ge.ORACLE_LIB); orc.zkp_oracle_init()
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    n = 7
+    v, mn, mx, seeds = workload(n, 21)
+    def prover(vals, mins, maxs, sd):
+        a = lambda x: np.array(list(x), dtype=np.uint64)
+        rc, out, lens, st = oracle_prove(orc, a(vals), a(mins), a(maxs), np.frombuffer(sd, dtype=np.uint8).copy(), threads=2)
+        assert rc == 0
+        return [out[i].tobytes() for i in range(len(vals))]
+    got = process_range_batch_sharded(list(map(int, v)), list(map(int, mn)), list(map(int, mx)), seeds.tobytes(), prover=prover)
+    rc, ref, lens, st = oracle_prove(orc, v, mn, mx, seeds, threads=2)
+    assert len(got) == n and all(got[i] == ref[i].tobytes() for i in range(n)), "sharded result differs from the unsharded one"
+    dist.barrier(); dist.destroy_process_group()
+    print("rank", os.environ["RANK"], "ok")
+""")
+
+
+def test_world_size_two_gloo(tmp_path, oracle_c):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29611", str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
