@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--window-budget", type=int, default=0)
+    ap.add_argument("--subbatches", type=int, default=0)
     args = ap.parse_args()
 
     import numpy as np
@@ -94,6 +95,8 @@ def main():
     L = _native.lib()
     if args.window_budget:
         L.zkp_hip_set_window_budget(args.window_budget)
+    if args.subbatches:
+        L.zkp_hip_set_subbatches(args.subbatches)
     _native.check(L.zkp_hip_init(local_rank), "zkp_hip_init")
 
     n = args.batch
@@ -106,7 +109,7 @@ def main():
     d_out = torch.zeros((n, PROOF_BYTES), dtype=torch.uint8, device=dev)
     d_len = torch.zeros(n, dtype=torch.int32, device=dev)
     d_st = torch.zeros(n, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream(device=dev)   # non-default stream: its handle is non-NULL, so the library launches on it
 
     def step():
         rc = L.zkp_hip_prove_range_batch_device(n, d_v.data_ptr(), d_mn.data_ptr(), d_mx.data_ptr(), 64, d_seeds.data_ptr(),
@@ -120,6 +123,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()

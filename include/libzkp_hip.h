@@ -68,8 +68,11 @@ void zkp_hip_profile_enable(int on);
 /* Synchronises, then returns accumulated MSM kernel time (ms), launch count, and table-entry gathers
  * (point additions) since the last reset. */
 int zkp_hip_profile_read(double* msm_ms, uint64_t* msm_launches, uint64_t* msm_point_adds, int reset);
-/* Tunables: windows of MSM work per workgroup chunk (default 128). Takes effect at the next zkp_hip_init. */
+/* Tunables.  window budget: windows of MSM work per workgroup (multiple of 32; 0 = chosen per launch from the batch
+ * size and the number of resident workgroups).  sub-batches: independent slices of a batch run on separate HIP streams
+ * so one slice's latency-bound per-proof steps can overlap another's MSM (default 1: measured slower; takes effect at the next zkp_hip_init). */
 void zkp_hip_set_window_budget(uint32_t budget);
+void zkp_hip_set_subbatches(uint32_t n);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ RANGE_PROOF_BYTES = 1478
 # symbols declared in include/libzkp_hip.h (checked by tests/test_abi.py)
 EXPORTS = (
     "zkp_hip_init", "zkp_hip_shutdown", "zkp_hip_last_error", "zkp_hip_prove_range_batch",
-    "zkp_hip_prove_range_batch_device", "zkp_hip_profile_enable", "zkp_hip_profile_read", "zkp_hip_set_window_budget",
+    "zkp_hip_prove_range_batch_device", "zkp_hip_profile_enable", "zkp_hip_profile_read", "zkp_hip_set_window_budget", "zkp_hip_set_subbatches",
 )
 
 _lib = None
@@ -22,6 +22,19 @@ class NativeError(RuntimeError):
     pass
 
 
+def _preload_hip_runtime():
+    """When PyTorch-ROCm is installed it ships its own libamdhip64.so.7; two HIP runtimes in one process cannot both
+    see the GPU.  Loading torch's copy first (same soname) makes libzkp_hip.so and torch share one runtime whichever
+    is imported first.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -29,6 +42,7 @@ def lib():
             raise NativeError(
                 "libzkp_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                 "libzkp_amd has no CPU fallback")
+        _preload_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         u64, u32, i32, vp = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p
         L.zkp_hip_init.argtypes = [ctypes.c_int]
@@ -45,6 +59,8 @@ def lib():
         L.zkp_hip_profile_read.restype = ctypes.c_int
         L.zkp_hip_set_window_budget.argtypes = [u32]
         L.zkp_hip_set_window_budget.restype = None
+        L.zkp_hip_set_subbatches.argtypes = [u32]
+        L.zkp_hip_set_subbatches.restype = None
         _lib = L
     return _lib
 

@@ -75,8 +75,122 @@ ZKP_HD inline sc sc_from_wide(const uint32_t w[16]) {   // Scalar::from_bytes_mo
     return sc_add(sc_montmul(lo, sc_R2()), sc_montmul(hi, sc_R3()));
 }
 
-// a^(l-2), fixed 4-bit window
-ZKP_HD inline sc sc_invert(const sc& a) {
+// ---- modular inverse by Bernstein-Yang "safegcd" divsteps (constant-time, branch-free; 20 x 30 divsteps cover any
+// 256-bit input, bound 590).  ~10k VALU instructions against ~78k for the Fermat ladder: the per-proof challenge
+// inversions (y, u_1..u_6) sit on the serial critical path of every inner-product round.
+// Signed 30-bit limbs, value = sum v[i] * 2^(30 i).
+struct sc_s30 { int32_t v[9]; };
+#define ZKP_SC_L30(i) ((i) == 0 ? 0x1cf5d3ed : (i) == 1 ? 0x20498c69 : (i) == 2 ? 0x2f79cd65 : (i) == 3 ? 0x37be77a8 : (i) == 4 ? 0x14 : (i) == 8 ? 0x1000 : 0)
+#define ZKP_SC_L_INV30 0x2dab81e5u
+
+struct sc_trans2x2 { int32_t u, v, q, r; };
+
+ZKP_HD inline int32_t sc_divsteps_30(int32_t zeta, uint32_t f0, uint32_t g0, sc_trans2x2& t) {
+    uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+    for (int i = 0; i < 30; i++) {
+        uint32_t mask1 = (uint32_t)(zeta >> 31);
+        const uint32_t mask2 = 0u - (g & 1u);
+        const uint32_t x = (f ^ mask1) - mask1, y = (u ^ mask1) - mask1, z = (v ^ mask1) - mask1;
+        g += x & mask2; q += y & mask2; r += z & mask2;
+        mask1 &= mask2;
+        zeta = (int32_t)((uint32_t)zeta ^ mask1) - 1;
+        f += g & mask1; u += q & mask1; v += r & mask1;
+        g >>= 1; u <<= 1; v <<= 1;
+    }
+    t.u = (int32_t)u; t.v = (int32_t)v; t.q = (int32_t)q; t.r = (int32_t)r;
+    return zeta;
+}
+// (d, e) <- t * (d, e) / 2^30 mod l, keeping d, e in (-2l, l)
+ZKP_HD inline void sc_update_de_30(sc_s30& d, sc_s30& e, const sc_trans2x2& t) {
+    const int32_t M30 = (int32_t)(0xffffffffu >> 2);
+    const int32_t u = t.u, v = t.v, q = t.q, r = t.r;
+    const int32_t sd = d.v[8] >> 31, se = e.v[8] >> 31;
+    int32_t md = (u & sd) + (v & se), me = (q & sd) + (r & se);
+    int32_t di = d.v[0], ei = e.v[0];
+    int64_t cd = (int64_t)u * di + (int64_t)v * ei, ce = (int64_t)q * di + (int64_t)r * ei;
+    md -= (int32_t)((ZKP_SC_L_INV30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
+    me -= (int32_t)((ZKP_SC_L_INV30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+    cd += (int64_t)ZKP_SC_L30(0) * md; ce += (int64_t)ZKP_SC_L30(0) * me;
+    cd >>= 30; ce >>= 30;
+    ZKP_UNROLL for (int i = 1; i < 9; i++) {
+        di = d.v[i]; ei = e.v[i];
+        cd += (int64_t)u * di + (int64_t)v * ei; ce += (int64_t)q * di + (int64_t)r * ei;
+        cd += (int64_t)ZKP_SC_L30(i) * md; ce += (int64_t)ZKP_SC_L30(i) * me;
+        d.v[i - 1] = (int32_t)cd & M30; cd >>= 30;
+        e.v[i - 1] = (int32_t)ce & M30; ce >>= 30;
+    }
+    d.v[8] = (int32_t)cd; e.v[8] = (int32_t)ce;
+}
+// (f, g) <- t * (f, g) / 2^30 (exact)
+ZKP_HD inline void sc_update_fg_30(sc_s30& f, sc_s30& g, const sc_trans2x2& t) {
+    const int32_t M30 = (int32_t)(0xffffffffu >> 2);
+    const int32_t u = t.u, v = t.v, q = t.q, r = t.r;
+    int32_t fi = f.v[0], gi = g.v[0];
+    int64_t cf = (int64_t)u * fi + (int64_t)v * gi, cg = (int64_t)q * fi + (int64_t)r * gi;
+    cf >>= 30; cg >>= 30;
+    ZKP_UNROLL for (int i = 1; i < 9; i++) {
+        fi = f.v[i]; gi = g.v[i];
+        cf += (int64_t)u * fi + (int64_t)v * gi; cg += (int64_t)q * fi + (int64_t)r * gi;
+        f.v[i - 1] = (int32_t)cf & M30; cf >>= 30;
+        g.v[i - 1] = (int32_t)cg & M30; cg >>= 30;
+    }
+    f.v[8] = (int32_t)cf; g.v[8] = (int32_t)cg;
+}
+// raw words (any value < l) -> raw words of its inverse mod l (0 -> 0)
+ZKP_HD inline sc sc_modinv_raw(const sc& x) {
+    const int32_t M30 = (int32_t)(0xffffffffu >> 2);
+    sc_s30 d, e, f, g;
+    ZKP_UNROLL for (int i = 0; i < 9; i++) { d.v[i] = 0; e.v[i] = 0; f.v[i] = ZKP_SC_L30(i); }
+    e.v[0] = 1;
+    // 8 x 32 -> 9 x 30
+    ZKP_UNROLL for (int i = 0; i < 9; i++) {
+        const int bit = 30 * i, w = bit >> 5, sh = bit & 31;
+        uint32_t val = x.v[w] >> sh;
+        if (sh > 2 && w + 1 < 8) val |= x.v[w + 1] << (32 - sh);
+        g.v[i] = (int32_t)(val & (uint32_t)M30);
+    }
+    int32_t zeta = -1;
+    for (int it = 0; it < 20; it++) {
+        sc_trans2x2 t;
+        zeta = sc_divsteps_30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+        sc_update_de_30(d, e, t);
+        sc_update_fg_30(f, g, t);
+    }
+    // now g = 0 and f = +-1; inverse = sign(f) * d, d in (-2l, l)
+    const int32_t neg = f.v[8] >> 31;                       // all ones if f = -1
+    int64_t c = 0; int32_t lim[9];
+    ZKP_UNROLL for (int i = 0; i < 9; i++) { c += (int64_t)((d.v[i] ^ neg) - neg); lim[i] = (int32_t)c & M30; c >>= 30; }
+    lim[8] |= (int32_t)((uint32_t)c << 30);                 // keep the sign in the top limb (value in (-2l, 2l))
+    // add l while negative (at most twice), then subtract l if >= l
+    for (int rep = 0; rep < 2; rep++) {
+        const int32_t m = lim[8] >> 31;
+        int64_t cc = 0;
+        ZKP_UNROLL for (int i = 0; i < 8; i++) { cc += (int64_t)lim[i] + (ZKP_SC_L30(i) & m); lim[i] = (int32_t)cc & M30; cc >>= 30; }
+        lim[8] = (int32_t)(cc + lim[8] + (ZKP_SC_L30(8) & m));
+    }
+    {
+        int64_t cc = 0; int32_t sub[9];
+        ZKP_UNROLL for (int i = 0; i < 8; i++) { cc += (int64_t)lim[i] - ZKP_SC_L30(i); sub[i] = (int32_t)cc & M30; cc >>= 30; }
+        sub[8] = (int32_t)(cc + lim[8] - ZKP_SC_L30(8));
+        const bool ge = sub[8] >= 0;
+        ZKP_UNROLL for (int i = 0; i < 9; i++) lim[i] = ge ? sub[i] : lim[i];
+    }
+    // 9 x 30 -> 8 x 32
+    sc r;
+    ZKP_UNROLL for (int w = 0; w < 8; w++) {
+        const int bit = 32 * w, i = bit / 30, sh = bit % 30;
+        uint32_t val = (uint32_t)lim[i] >> sh;
+        val |= (uint32_t)lim[i + 1] << (30 - sh);
+        if (30 - sh + 30 < 32 && i + 2 < 9) val |= (uint32_t)lim[i + 2] << (60 - sh);
+        r.v[w] = val;
+    }
+    return r;
+}
+// inverse in the Montgomery domain: (aR)^-1 * R^3 / R = a^-1 R
+ZKP_HD inline sc sc_invert(const sc& a) { return sc_montmul(sc_modinv_raw(a), sc_R3()); }
+
+// a^(l-2) by a fixed 4-bit window ladder (kept as the independent cross-check of sc_invert in the tests)
+ZKP_HD inline sc sc_invert_fermat(const sc& a) {
     sc tbl[16];
     tbl[0] = sc_one(); tbl[1] = a;
     for (int i = 2; i < 16; i++) tbl[i] = sc_montmul(tbl[i - 1], a);
@@ -87,7 +201,7 @@ ZKP_HD inline sc sc_invert(const sc& a) {
         const uint32_t d = (e[nib >> 3] >> ((nib & 7) * 4)) & 15u;
         if (d) {
             sc m = tbl[1];
-            for (int k = 2; k < 16; k++) m = (d == (uint32_t)k) ? tbl[k] : m;   // select without dynamic register indexing
+            for (int k = 2; k < 16; k++) m = (d == (uint32_t)k) ? tbl[k] : m;
             acc = sc_montmul(acc, m);
         }
     }

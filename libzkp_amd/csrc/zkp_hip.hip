@@ -89,6 +89,7 @@ __global__ void __launch_bounds__(TW) k_reduce(ReduceView R) {
 //           the sub-table stays in that XCD's 4 MB L2 (blocks b and b+8 share an XCD).
 static constexpr int MSM_TB = 256;
 static constexpr uint32_t SUBTAB_V4 = SUBTAB_W / 4;   // 960 x 16 bytes
+static_assert(SUBTAB_V4 > 3 * 256 && SUBTAB_V4 <= 4 * 256, "prefetch pattern assumes 768 < 960 <= 1024");
 
 __global__ void __launch_bounds__(MSM_TB) k_msm(MsmView m, uint32_t ngroups, uint32_t nblocks) {
     __shared__ uint4 lds4[SUBTAB_V4];
@@ -102,26 +103,31 @@ __global__ void __launch_bounds__(MSM_TB) k_msm(MsmView m, uint32_t ngroups, uin
     const uint32_t s1 = m.chunk_begin[chunk + 1];
     uint32_t s = m.chunk_begin[chunk], w = 0;
     ge acc = ge_identity();
-    uint4 pre[4];
-    auto prefetch = [&](uint32_t base, uint32_t win) {
-        const uint4* src = reinterpret_cast<const uint4*>(m.table + ((size_t)base * NWIN + win) * SUBTAB_W);
-        ZKP_UNROLL for (int q = 0; q < 4; q++) { const uint32_t idx = tid + q * MSM_TB; if (idx < SUBTAB_V4) pre[q] = src[idx]; }
-    };
-    if (s < s1) prefetch(m.slot_base[s], 0);
+    uint4 pre0, pre1, pre2, pre3;
+    pre0 = pre1 = pre2 = pre3 = make_uint4(0, 0, 0, 0);
+#define ZKP_MSM_PREFETCH(base_, win_)                                                                              \
+    do {                                                                                                           \
+        const uint4* src_ = reinterpret_cast<const uint4*>(m.table + ((size_t)(base_) * NWIN + (win_)) * SUBTAB_W); \
+        pre0 = src_[tid]; pre1 = src_[tid + MSM_TB]; pre2 = src_[tid + 2 * MSM_TB];                                 \
+        if (tid + 3 * MSM_TB < SUBTAB_V4) pre3 = src_[tid + 3 * MSM_TB];                                            \
+    } while (0)
+    if (s < s1) ZKP_MSM_PREFETCH(m.slot_base[s], 0);
     uint32_t dw = 0;
     while (s < s1) {
         const uint32_t nwin = m.slot_nwin[s];
         __syncthreads();   // previous window's gathers are done
-        ZKP_UNROLL for (int q = 0; q < 4; q++) { const uint32_t idx = tid + q * MSM_TB; if (idx < SUBTAB_V4) lds4[idx] = pre[q]; }
+        lds4[tid] = pre0; lds4[tid + MSM_TB] = pre1; lds4[tid + 2 * MSM_TB] = pre2;
+        if (tid + 3 * MSM_TB < SUBTAB_V4) lds4[tid + 3 * MSM_TB] = pre3;
         __syncthreads();
         uint32_t ns = s, nw = w + 1;
         if (nw == nwin) { ns = s + 1; nw = 0; }
-        if (ns < s1) prefetch(m.slot_base[ns], nw);   // in flight during the point addition below
+        if (ns < s1) ZKP_MSM_PREFETCH(m.slot_base[ns], nw);   // in flight during the point addition below
         if ((w & 3u) == 0) dw = active ? m.digits[((size_t)s * 8 + (w >> 2)) * m.rows + row] : 0u;
         const int32_t d = (int32_t)(int8_t)(dw >> (8 * (w & 3u)));
         if (d != 0) acc = msm_accumulate_digit(acc, d, reinterpret_cast<const uint32_t*>(lds4));
         s = ns; w = nw;
     }
+#undef ZKP_MSM_PREFETCH
     if (active) st_ge(m.partial, chunk, row, m.rows, acc);
 }
 
@@ -139,21 +145,30 @@ int fail(int code, const std::string& msg) { t_err = msg; return code; }
 struct DevLayout {
     uint16_t *slot_base = nullptr, *chunk_begin = nullptr, *target_chunk_begin = nullptr;
     uint8_t* slot_nwin = nullptr;
-    uint32_t nslots = 0, nchunks = 0, ntargets = 0;
+    uint32_t nslots = 0, nchunks = 0, ntargets = 0, max_chunk_windows = 0, max_target_chunks = 0;
     uint64_t adds_per_row = 0;   // sum of nwin = point additions per proof in this launch
+};
+// one layout per chunk size T (windows of work per workgroup = 32*T); the launch picks T from the batch size
+constexpr int MAXT = 8;
+struct LayoutSet { DevLayout t[MAXT + 1]; };
+
+struct SubBatch {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    void* ws = nullptr;
+    uint32_t capM = 0, capC = 0;
 };
 
 struct Ctx {
     bool ready = false;
     int device = 0;
+    int num_cu = 256, msm_blocks_per_cu = 3;
     hipStream_t stream = nullptr;
+    hipEvent_t start_ev = nullptr;
     uint32_t* d_table = nullptr;
-    uint32_t budget = 128;
-    DevLayout p1, p2, rd[6], ct;
+    LayoutSet p1, p2, rd[6], ct;
     uint32_t max_chunks = 0;
-    // workspace
-    uint32_t capM = 0, capC = 0;
-    void* ws = nullptr;
+    std::vector<SubBatch> sub;
     // profiling
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -162,11 +177,22 @@ struct Ctx {
 };
 Ctx g;
 std::mutex g_mu;
-uint32_t g_budget_request = 128;
+uint32_t g_budget_request = 0;     // 0 = choose per launch
+uint32_t g_subbatches = 1;         // >1: independent slices on separate streams (measured slower on MI355X: see DESIGN.md)
 
 int upload_layout(DevLayout& D, const MsmLayout& L) {
     D.nslots = L.nslots(); D.nchunks = L.nchunks(); D.ntargets = L.ntargets();
     D.adds_per_row = 0; for (uint8_t x : L.slot_nwin) D.adds_per_row += x;
+    D.max_chunk_windows = 0;
+    for (uint32_t c = 0; c < D.nchunks; c++) {
+        uint32_t wsum = 0; for (uint32_t q = L.chunk_begin[c]; q < L.chunk_begin[c + 1]; q++) wsum += L.slot_nwin[q];
+        if (wsum > D.max_chunk_windows) D.max_chunk_windows = wsum;
+    }
+    D.max_target_chunks = 0;
+    for (uint32_t t = 0; t < D.ntargets; t++) {
+        const uint32_t k = L.target_chunk_begin[t + 1] - L.target_chunk_begin[t];
+        if (k > D.max_target_chunks) D.max_target_chunks = k;
+    }
     HIP_TRY(hipMalloc(&D.slot_base, L.slot_base.size() * 2));
     HIP_TRY(hipMalloc(&D.chunk_begin, L.chunk_begin.size() * 2));
     HIP_TRY(hipMalloc(&D.target_chunk_begin, L.target_chunk_begin.size() * 2));
@@ -181,6 +207,28 @@ void free_layout(DevLayout& D) {
     (void)hipFree(D.slot_base); (void)hipFree(D.chunk_begin); (void)hipFree(D.target_chunk_begin); (void)hipFree(D.slot_nwin);
     D = DevLayout();
 }
+template <class F> int upload_set(LayoutSet& S, F make) {
+    for (int T = 1; T <= MAXT; T++) { int rc = upload_layout(S.t[T], make(32u * T)); if (rc) return rc; if (S.t[T].nchunks > g.max_chunks) g.max_chunks = S.t[T].nchunks; }
+    return 0;
+}
+void free_set(LayoutSet& S) { for (int T = 1; T <= MAXT; T++) free_layout(S.t[T]); }
+
+// Chunk size for one launch: the grid is nchunks * ceil(rows/256) workgroups, msm_blocks_per_cu * num_cu of which are
+// resident at a time; cost = (#rounds of resident workgroups) * (windows per workgroup) + the serial partial-sum tail.
+const DevLayout& pick_layout(const LayoutSet& S, uint32_t rows) {
+    if (g_budget_request) { int T = (int)(g_budget_request / 32); if (T < 1) T = 1; if (T > MAXT) T = MAXT; return S.t[T]; }
+    const double resident = (double)g.num_cu * g.msm_blocks_per_cu;
+    const uint32_t groups = (rows + 255) / 256;
+    int best = 1; double best_cost = 1e300;
+    for (int T = 1; T <= MAXT; T++) {
+        const DevLayout& D = S.t[T];
+        const double blocks = (double)D.nchunks * groups;
+        const double rounds = blocks <= resident ? 1.0 : blocks / resident + 0.5;   // partial last round costs about half
+        const double cost = rounds * D.max_chunk_windows * 5.6 + D.max_target_chunks * 2.6;
+        if (cost < best_cost) { best_cost = cost; best = T; }
+    }
+    return S.t[best];
+}
 
 int init_locked(int device) {
     if (g.ready) {
@@ -193,7 +241,12 @@ int init_locked(int device) {
     if (device < 0 || device >= ndev) return fail(ZKP_HIP_E_ARGUMENT, "zkp_hip_init: bad device index");
     HIP_TRY(hipSetDevice(device));
     g.device = device;
+    hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
+    g.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_msm, MSM_TB, 0) == hipSuccess && occ > 0) g.msm_blocks_per_cu = occ;
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&g.start_ev, hipEventDisableTiming));
     // generator tables (one-time, host)
     const size_t words = (size_t)NBASE * NWIN * SUBTAB_W;
     std::vector<uint32_t> tab(words);
@@ -209,15 +262,18 @@ int init_locked(int device) {
     }
     HIP_TRY(hipMalloc(&g.d_table, words * 4));
     HIP_TRY(hipMemcpy(g.d_table, tab.data(), words * 4, hipMemcpyHostToDevice));
-    g.budget = g_budget_request ? g_budget_request : 128;
     int rc;
-    if ((rc = upload_layout(g.p1, layout_phase1(g.budget)))) return rc;
-    if ((rc = upload_layout(g.p2, layout_phase2(g.budget)))) return rc;
-    for (uint32_t r = 0; r < 6; r++) if ((rc = upload_layout(g.rd[r], layout_round(r, g.budget)))) return rc;
-    if ((rc = upload_layout(g.ct, layout_ctask(g.budget)))) return rc;
-    g.max_chunks = g.p1.nchunks;
-    if (g.p2.nchunks > g.max_chunks) g.max_chunks = g.p2.nchunks;
-    for (uint32_t r = 0; r < 6; r++) if (g.rd[r].nchunks > g.max_chunks) g.max_chunks = g.rd[r].nchunks;
+    g.max_chunks = 0;
+    if ((rc = upload_set(g.p1, layout_phase1))) return rc;
+    if ((rc = upload_set(g.p2, layout_phase2))) return rc;
+    for (uint32_t r = 0; r < 6; r++) if ((rc = upload_set(g.rd[r], [r](uint32_t b) { return layout_round(r, b); }))) return rc;
+    if ((rc = upload_set(g.ct, layout_ctask))) return rc;
+    uint32_t ns = g_subbatches; if (ns < 1) ns = 1; if (ns > 8) ns = 8;
+    g.sub.resize(ns);
+    for (auto& sb : g.sub) {
+        HIP_TRY(hipStreamCreateWithFlags(&sb.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&sb.done, hipEventDisableTiming));
+    }
     g.ready = true;
     return 0;
 }
@@ -259,13 +315,13 @@ size_t carve(uint8_t* base, uint32_t M, uint32_t C, uint32_t max_chunks, Ws* w) 
     return off;
 }
 
-int ensure_workspace(uint32_t M, uint32_t C) {
-    if (M <= g.capM && C <= g.capC && g.ws) return 0;
-    if (g.ws) { HIP_TRY(hipFree(g.ws)); g.ws = nullptr; }
-    const uint32_t nm = M > g.capM ? M : g.capM, nc = C > g.capC ? C : g.capC;
+int ensure_workspace(SubBatch& sb, uint32_t M, uint32_t C) {
+    if (M <= sb.capM && C <= sb.capC && sb.ws) return 0;
+    if (sb.ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(sb.ws)); sb.ws = nullptr; }
+    const uint32_t nm = M > sb.capM ? M : sb.capM, nc = C > sb.capC ? C : sb.capC;
     const size_t bytes = carve(nullptr, nm, nc, g.max_chunks, nullptr);
-    HIP_TRY(hipMalloc(&g.ws, bytes));
-    g.capM = nm; g.capC = nc;
+    HIP_TRY(hipMalloc(&sb.ws, bytes));
+    sb.capM = nm; sb.capC = nc;
     return 0;
 }
 
@@ -292,6 +348,12 @@ int launch_reduce(const DevLayout& D, uint32_t rows, const uint32_t* partial, ui
     k_reduce<<<dim3((rows + TW - 1) / TW, D.ntargets), TW, 0, st>>>(R);
     return 0;
 }
+int msm_and_encode(const LayoutSet& S, uint32_t rows, const uint32_t* digits, uint32_t* partial, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
+    const DevLayout& D = pick_layout(S, rows);
+    int rc = launch_msm(D, rows, digits, partial, st);
+    if (rc) return rc;
+    return launch_reduce(D, rows, partial, enc, out_off, out, st);
+}
 
 // the whole prover for M jobs + C commitment tasks already described in the workspace
 int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st) {
@@ -299,24 +361,20 @@ int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st) {
     const dim3 gj((M + TB - 1) / TB), gw((M + TW - 1) / TW);
     if (C) {
         k_ctask<<<(C + TB - 1) / TB, TB, 0, st>>>(w.T);
-        if ((rc = launch_msm(g.ct, C, w.T.digits, w.ct_partial, st))) return rc;
-        if ((rc = launch_reduce(g.ct, C, w.ct_partial, w.ct_enc, w.ct_off, w.V.out, st))) return rc;
+        if ((rc = msm_and_encode(g.ct, C, w.T.digits, w.ct_partial, w.ct_enc, w.ct_off, w.V.out, st))) return rc;
     }
     k_tape<<<dim3(gj.x, TAPE_SLOTS + 1), TB, 0, st>>>(w.V);
-    if ((rc = launch_msm(g.p1, M, w.V.d1, w.partial, st))) return rc;
-    if ((rc = launch_reduce(g.p1, M, w.partial, w.V.enc, nullptr, nullptr, st))) return rc;
+    if ((rc = msm_and_encode(g.p1, M, w.V.d1, w.partial, w.V.enc, nullptr, nullptr, st))) return rc;
     k_transcript1<<<gw, TW, 0, st>>>(w.V);
     k_poly<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V);
     k_poly_sum<<<gw, TW, 0, st>>>(w.V);
-    if ((rc = launch_msm(g.p2, M, w.V.d2, w.partial, st))) return rc;
-    if ((rc = launch_reduce(g.p2, M, w.partial, w.V.enc, nullptr, nullptr, st))) return rc;
+    if ((rc = msm_and_encode(g.p2, M, w.V.d2, w.partial, w.V.enc, nullptr, nullptr, st))) return rc;
     k_transcript2<<<gw, TW, 0, st>>>(w.V);
     k_lr_init<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V);
     for (uint32_t r = 0; r < 6; r++) {
         k_round_prep<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V, r);
         k_round_sum<<<gw, TW, 0, st>>>(w.V, r);
-        if ((rc = launch_msm(g.rd[r], M, w.V.dr, w.partial, st))) return rc;
-        if ((rc = launch_reduce(g.rd[r], M, w.partial, w.V.enc, nullptr, nullptr, st))) return rc;
+        if ((rc = msm_and_encode(g.rd[r], M, w.V.dr, w.partial, w.V.enc, nullptr, nullptr, st))) return rc;
         k_transcript_round<<<gw, TW, 0, st>>>(w.V, r);
     }
     HIP_TRY(hipGetLastError());
@@ -328,22 +386,39 @@ __global__ void k_any_failed(const int32_t* status, uint32_t n, int* flag) {
     if (i < n && status[i] != 0) atomicOr(flag, 1);
 }
 
+// Ops are independent, so the batch is cut into contiguous sub-batches that run the whole kernel sequence on their
+// own streams: while one sub-batch is in a latency-bound per-proof step (transcript, inversion, encoding) the other's
+// MSM keeps the CUs busy.  `st` (the caller's stream) is forked into the sub-streams and joined again.
 int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_t* d_min, const uint64_t* d_max,
                               const uint8_t* d_seeds, uint8_t* d_out, uint64_t stride, uint32_t* d_out_len, int32_t* d_status,
                               hipStream_t st, int* any_failed) {
     if (n == 0) { if (any_failed) *any_failed = 0; return 0; }
     if (n > (1u << 30)) return fail(ZKP_HIP_E_ARGUMENT, "batch too large");
     if (stride < RANGE_PROOF_BYTES) return fail(ZKP_HIP_E_ARGUMENT, "stride must be >= 1478");
-    const uint32_t C = (uint32_t)n, M = 2 * C;
     int rc;
-    if ((rc = ensure_workspace(M, C))) return rc;
-    Ws w; carve((uint8_t*)g.ws, M, C, g.max_chunks, &w);
-    w.V.seeds = reinterpret_cast<const uint32_t*>(d_seeds); w.T.seeds = w.V.seeds; w.V.out = d_out;
-    k_build_range<<<(C + TB - 1) / TB, TB, 0, st>>>(w.J, C, d_value, d_min, d_max, d_out, stride, d_out_len, d_status);
-    if ((rc = run_pipeline(w, M, C, st))) return rc;
+    uint32_t nsub = (uint32_t)g.sub.size();
+    if (n < 512) nsub = 1;                       // small batches: one stream
+    const uint64_t per = (n + nsub - 1) / nsub;
+    HIP_TRY(hipEventRecord(g.start_ev, st));
+    for (uint32_t h = 0; h < nsub; h++) {
+        const uint64_t lo = h * per, hi = (lo + per < n) ? lo + per : n;
+        if (lo >= hi) continue;
+        SubBatch& sb = g.sub[h];
+        const uint32_t C = (uint32_t)(hi - lo), M = 2 * C;
+        if ((rc = ensure_workspace(sb, M, C))) return rc;
+        Ws w; carve((uint8_t*)sb.ws, M, C, g.max_chunks, &w);
+        w.V.seeds = reinterpret_cast<const uint32_t*>(d_seeds + 32 * lo); w.T.seeds = w.V.seeds;
+        w.V.out = d_out + lo * stride;
+        HIP_TRY(hipStreamWaitEvent(sb.stream, g.start_ev, 0));
+        k_build_range<<<(C + TB - 1) / TB, TB, 0, sb.stream>>>(w.J, C, d_value + lo, d_min + lo, d_max + lo, w.V.out, stride, d_out_len + lo, d_status + lo);
+        if ((rc = run_pipeline(w, M, C, sb.stream))) return rc;
+        HIP_TRY(hipEventRecord(sb.done, sb.stream));
+        HIP_TRY(hipStreamWaitEvent(st, sb.done, 0));
+    }
     if (any_failed) {
+        Ws w; carve((uint8_t*)g.sub[0].ws, g.sub[0].capM, g.sub[0].capC, g.max_chunks, &w);
         HIP_TRY(hipMemsetAsync(w.flag, 0, sizeof(int), st));
-        k_any_failed<<<(C + TB - 1) / TB, TB, 0, st>>>(d_status, C, w.flag);
+        k_any_failed<<<(uint32_t)((n + TB - 1) / TB), TB, 0, st>>>(d_status, (uint32_t)n, w.flag);
         HIP_TRY(hipMemcpyAsync(any_failed, w.flag, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
@@ -357,6 +432,7 @@ extern "C" {
 
 const char* zkp_hip_last_error(void) { return t_err.c_str(); }
 void zkp_hip_set_window_budget(uint32_t budget) { g_budget_request = budget; }
+void zkp_hip_set_subbatches(uint32_t n) { g_subbatches = n; }
 
 int zkp_hip_init(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -367,11 +443,13 @@ void zkp_hip_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g.ready) return;
     (void)hipSetDevice(g.device);
-    (void)hipStreamSynchronize(g.stream);
-    (void)hipFree(g.ws); (void)hipFree(g.d_table);
-    free_layout(g.p1); free_layout(g.p2); free_layout(g.ct);
-    for (auto& d : g.rd) free_layout(d);
+    (void)hipDeviceSynchronize();
+    for (auto& sb : g.sub) { (void)hipFree(sb.ws); (void)hipStreamDestroy(sb.stream); (void)hipEventDestroy(sb.done); }
+    (void)hipFree(g.d_table);
+    free_set(g.p1); free_set(g.p2); free_set(g.ct);
+    for (auto& d : g.rd) free_set(d);
     for (auto& e : g.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    (void)hipEventDestroy(g.start_ev);
     (void)hipStreamDestroy(g.stream);
     g = Ctx();
 }

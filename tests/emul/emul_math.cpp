@@ -32,12 +32,12 @@ void emul_fe_loose(const uint32_t a[8], const uint32_t b[8], const uint32_t c[8]
 int emul_sqrt_ratio(const uint32_t u[8], const uint32_t v[8], uint32_t out[8]) {
     fe r; bool sq = fe_sqrt_ratio_m1(r, fe_fromwords(u), fe_fromwords(v)); fe_towords(out, r); return sq;
 }
-// scalar ops on raw canonical words: 0 mul, 1 add, 2 sub, 3 invert, 4 neg
+// scalar ops on raw canonical words: 0 mul, 1 add, 2 sub, 3 invert (safegcd), 4 neg, 5 invert (Fermat)
 void emul_sc_op(int op, const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) {
     sc x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32);
     x = sc_from_raw256(x); y = sc_from_raw256(y);
     sc r;
-    switch (op) { case 0: r = sc_mul(x, y); break; case 1: r = sc_add(x, y); break; case 2: r = sc_sub(x, y); break; case 3: r = sc_invert(x); break; default: r = sc_neg(x); }
+    switch (op) { case 0: r = sc_mul(x, y); break; case 1: r = sc_add(x, y); break; case 2: r = sc_sub(x, y); break; case 3: r = sc_invert(x); break; case 5: r = sc_invert_fermat(x); break; default: r = sc_neg(x); }
     r = sc_to_raw(r); memcpy(out, r.v, 32);
 }
 void emul_sc_from_wide(const uint32_t w[16], uint32_t out[8]) { sc r = sc_to_raw(sc_from_wide(w)); memcpy(out, r.v, 32); }

@@ -52,8 +52,11 @@ def test_scalars(emul):
         for op, f in ((0, a * b), (1, a + b), (2, a - b), (4, -a)):
             lib.emul_sc_op(op, W(a), W(b), out)
             assert I(out) == f % LL
-        if a and i < 20:
+        if a:                                   # safegcd inversion (product path)
             lib.emul_sc_op(3, W(a), W(b), out)
+            assert I(out) == pow(a, LL - 2, LL)
+        if a and i < 12:                        # Fermat ladder cross-check
+            lib.emul_sc_op(5, W(a), W(b), out)
             assert I(out) == pow(a, LL - 2, LL)
         dg = (ctypes.c_int8 * 32)()
         lib.emul_sc_recode(W(a), dg)
