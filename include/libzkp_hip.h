@@ -62,6 +62,19 @@ int zkp_hip_prove_range_batch_device(uint64_t n, const uint64_t* d_value, const 
                                      const uint8_t* d_seeds, uint8_t* d_out, uint64_t stride, uint32_t* d_out_len, int32_t* d_status,
                                      void* stream, int* any_failed);
 
+/* Replaces a loop of proof::threshold_proof::prove_threshold(values, threshold)
+ * (/root/reference/src/proof/threshold_proof.rs:12-32 -> bulletproofs.rs:309-366).  values = all ops' value lists
+ * concatenated, counts[i] = length of op i's list.  One 762-byte envelope (scheme 3) per op; stride >= 762. */
+int zkp_hip_prove_threshold_batch(uint64_t n, const uint64_t* values, const uint32_t* counts, const uint64_t* thresholds, uint32_t n_bits,
+                                  const uint8_t* seeds, uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status);
+
+/* Replaces a loop of proof::consistency_proof::prove_consistency(data)
+ * (/root/reference/src/proof/consistency_proof.rs:12-22 -> bulletproofs.rs:368-437).  data = all ops' lists concatenated.
+ * Envelope (scheme 6) size depends on the list length: zkp_hip_consistency_proof_bytes(count); stride >= the largest. */
+uint64_t zkp_hip_consistency_proof_bytes(uint32_t count);
+int zkp_hip_prove_consistency_batch(uint64_t n, const uint64_t* data, const uint32_t* counts, const uint8_t* seeds,
+                                    uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status);
+
 /* Kernel timing for the roofline line of bench.py: when enabled, every launch of the dominant kernel
  * (fixed-base MSM) is bracketed by hipEvents on its own stream. */
 void zkp_hip_profile_enable(int on);

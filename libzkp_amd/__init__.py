@@ -5,7 +5,8 @@ for the path in scope: range proofs and the batch driver. 
 HIP library behind the C ABI of include/libzkp_hip.h; there is no CPU fallback.
 """
 from .api import (  # noqa: F401
-    prove_range, prove_range_batch, create_proof_batch, batch_add_range_proof, batch_add_equality_proof,
+    prove_range, prove_range_batch, prove_threshold, prove_threshold_batch, prove_consistency, prove_consistency_batch,
+    create_proof_batch, batch_add_range_proof, batch_add_equality_proof,
     batch_add_threshold_proof, batch_add_membership_proof, batch_add_improvement_proof, batch_add_consistency_proof,
     process_batch, get_batch_status, clear_batch, benchmark_proof_generation, benchmark_proof_generation_numeric,
     ZkpBackendError,
@@ -13,7 +14,8 @@ from .api import (  # noqa: F401
 from ._native import NativeError  # noqa: F401
 
 __all__ = [
-    "prove_range", "prove_range_batch", "create_proof_batch", "batch_add_range_proof", "batch_add_equality_proof",
+    "prove_range", "prove_range_batch", "prove_threshold", "prove_threshold_batch", "prove_consistency", "prove_consistency_batch",
+    "create_proof_batch", "batch_add_range_proof", "batch_add_equality_proof",
     "batch_add_threshold_proof", "batch_add_membership_proof", "batch_add_improvement_proof", "batch_add_consistency_proof",
     "process_batch", "get_batch_status", "clear_batch", "benchmark_proof_generation", "benchmark_proof_generation_numeric",
     "NativeError", "ZkpBackendError",

@@ -12,7 +12,8 @@ RANGE_PROOF_BYTES = 1478
 # symbols declared in include/libzkp_hip.h (checked by tests/test_abi.py)
 EXPORTS = (
     "zkp_hip_init", "zkp_hip_shutdown", "zkp_hip_last_error", "zkp_hip_prove_range_batch",
-    "zkp_hip_prove_range_batch_device", "zkp_hip_profile_enable", "zkp_hip_profile_read", "zkp_hip_set_window_budget", "zkp_hip_set_subbatches",
+    "zkp_hip_prove_range_batch_device", "zkp_hip_prove_threshold_batch", "zkp_hip_prove_consistency_batch",
+    "zkp_hip_consistency_proof_bytes", "zkp_hip_profile_enable", "zkp_hip_profile_read", "zkp_hip_set_window_budget", "zkp_hip_set_subbatches",
 )
 
 _lib = None
@@ -53,6 +54,12 @@ def lib():
         L.zkp_hip_prove_range_batch.restype = ctypes.c_int
         L.zkp_hip_prove_range_batch_device.argtypes = [u64, vp, vp, vp, u32, vp, vp, u64, vp, vp, vp, ctypes.POINTER(ctypes.c_int)]
         L.zkp_hip_prove_range_batch_device.restype = ctypes.c_int
+        L.zkp_hip_prove_threshold_batch.argtypes = [u64, vp, vp, vp, u32, vp, vp, u64, vp, vp]
+        L.zkp_hip_prove_threshold_batch.restype = ctypes.c_int
+        L.zkp_hip_prove_consistency_batch.argtypes = [u64, vp, vp, vp, vp, u64, vp, vp]
+        L.zkp_hip_prove_consistency_batch.restype = ctypes.c_int
+        L.zkp_hip_consistency_proof_bytes.argtypes = [u32]
+        L.zkp_hip_consistency_proof_bytes.restype = u64
         L.zkp_hip_profile_enable.argtypes = [ctypes.c_int]
         L.zkp_hip_profile_enable.restype = None
         L.zkp_hip_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.c_int]

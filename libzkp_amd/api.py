@@ -80,6 +80,95 @@ def prove_range_batch(values, mins, maxs, seeds=None, device=None):
     return [out[i, : lens[i]].tobytes() for i in range(n)]
 
 
+def _seed_ptr(seeds, n):
+    if seeds is None:
+        return None, None
+    s = np.frombuffer(bytes(seeds), dtype=np.uint8) if not isinstance(seeds, np.ndarray) else seeds.astype(np.uint8).ravel()
+    if s.size != 32 * n:
+        raise ValueError("seeds must hold 32 bytes per op")
+    s = np.ascontiguousarray(s)
+    return s, _P(s)
+
+
+def _raise_backend(rc, st, what):
+    if rc < 0:
+        raise ZkpBackendError("Backend error: %s" % _native.last_error())
+    if rc > 0:
+        bad = int(np.nonzero(st)[0][0])
+        raise ZkpBackendError("Backend error: %s failed for op %d (status %d)" % (what, bad, int(st[bad])))
+
+
+def validate_threshold_params(values, threshold):
+    """validation.rs:30-47."""
+    if len(values) == 0:
+        raise ValueError("values cannot be empty")
+    total = sum(values)
+    if total > U64_MAX:
+        raise ValueError("integer overflow in sum calculation")
+    if total < threshold:
+        raise ValueError("sum %d is less than threshold %d" % (total, threshold))
+    return total
+
+
+def validate_consistency_params(data):
+    """validation.rs:75-88."""
+    if len(data) == 0:
+        raise ValueError("data cannot be empty")
+    if any(a > b for a, b in zip(data, data[1:])):
+        raise ValueError("data is not monotonic non-decreasing")
+
+
+def prove_threshold_batch(value_lists, thresholds, seeds=None):
+    """Batched prove_threshold (threshold_proof.rs:12-32): one 762-byte envelope per op."""
+    n = len(value_lists)
+    lists = [[_check_u64("value", x) for x in vl] for vl in value_lists]
+    thr = [_check_u64("threshold", t) for t in thresholds]
+    for vl, t in zip(lists, thr):
+        validate_threshold_params(vl, t)
+    if n == 0:
+        return []
+    flat = np.array([x for vl in lists for x in vl], dtype=np.uint64)
+    counts = np.array([len(vl) for vl in lists], dtype=np.uint32)
+    th = np.array(thr, dtype=np.uint64)
+    keep, sp = _seed_ptr(seeds, n)
+    stride = 762
+    out = np.zeros((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint32)
+    st = np.zeros(n, dtype=np.int32)
+    rc = _native.lib().zkp_hip_prove_threshold_batch(n, _P(flat), _P(counts), _P(th), 64, sp, _P(out), stride, _P(lens), _P(st))
+    _raise_backend(rc, st, "threshold proof generation")
+    return [out[i, : lens[i]].tobytes() for i in range(n)]
+
+
+def prove_consistency_batch(data_lists, seeds=None):
+    """Batched prove_consistency (consistency_proof.rs:12-22)."""
+    n = len(data_lists)
+    lists = [[_check_u64("value", x) for x in dl] for dl in data_lists]
+    for dl in lists:
+        validate_consistency_params(dl)
+    if n == 0:
+        return []
+    L = _native.lib()
+    flat = np.array([x for dl in lists for x in dl], dtype=np.uint64)
+    counts = np.array([len(dl) for dl in lists], dtype=np.uint32)
+    stride = max(int(L.zkp_hip_consistency_proof_bytes(int(c))) for c in counts)
+    keep, sp = _seed_ptr(seeds, n)
+    out = np.zeros((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint32)
+    st = np.zeros(n, dtype=np.int32)
+    rc = L.zkp_hip_prove_consistency_batch(n, _P(flat), _P(counts), sp, _P(out), stride, _P(lens), _P(st))
+    _raise_backend(rc, st, "consistency proof generation")
+    return [out[i, : lens[i]].tobytes() for i in range(n)]
+
+
+def prove_threshold(values, threshold):
+    return prove_threshold_batch([list(values)], [threshold])[0]
+
+
+def prove_consistency(data):
+    return prove_consistency_batch([list(data)])[0]
+
+
 def prove_range(value, min, max):  # noqa: A002  (reference argument names)
     value, mn, mx = _check_u64("value", value), _check_u64("min", min), _check_u64("max", max)
     validate_range_params(value, mn, mx)
@@ -123,13 +212,7 @@ def batch_add_equality_proof(batch_id, val1, val2):
 
 def batch_add_threshold_proof(batch_id, values, threshold):
     values = [_check_u64("value", x) for x in values]
-    if not values:
-        raise ValueError("values cannot be empty")
-    total = sum(values)
-    if total > U64_MAX:
-        raise ValueError("integer overflow in sum calculation")
-    if total < threshold:
-        raise ValueError("sum %d is less than threshold %d" % (total, threshold))
+    validate_threshold_params(values, _check_u64("threshold", threshold))
     _with_batch(batch_id, ("threshold", tuple(values), threshold))
 
 
@@ -149,10 +232,7 @@ def batch_add_improvement_proof(batch_id, old, new):
 
 def batch_add_consistency_proof(batch_id, data):
     data = [_check_u64("value", x) for x in data]
-    if not data:
-        raise ValueError("data cannot be empty")
-    if any(a > b for a, b in zip(data, data[1:])):
-        raise ValueError("data is not monotonic non-decreasing")
+    validate_consistency_params(data)
     _with_batch(batch_id, ("consistency", tuple(data)))
 
 
@@ -163,10 +243,29 @@ def process_batch(batch_id, seeds=None):
             raise ValueError("Invalid batch ID: %d" % batch_id)
         ops = _registry.pop(batch_id)
     for op in ops:
-        if op[0] != "range":
-            backend = {"equality": "Groth16", "membership": "Groth16", "improvement": "STARK"}.get(op[0], "Bulletproofs")
+        if op[0] not in ("range", "threshold", "consistency"):
+            backend = {"equality": "Groth16", "membership": "Groth16", "improvement": "STARK"}[op[0]]
             raise NotImplementedError(_OUT_OF_SCOPE % (op[0], backend))
-    return prove_range_batch([o[1] for o in ops], [o[2] for o in ops], [o[3] for o in ops], seeds=seeds)
+    # bucket by variant (one batched device call each), then restore insertion order (batch.rs:123-131 is order-preserving)
+    seeds = None if seeds is None else bytes(seeds)
+    if seeds is not None and len(seeds) != 32 * len(ops):
+        raise ValueError("seeds must hold 32 bytes per op")
+    out = [None] * len(ops)
+    for kind in ("range", "threshold", "consistency"):
+        idx = [i for i, o in enumerate(ops) if o[0] == kind]
+        if not idx:
+            continue
+        sd = None if seeds is None else b"".join(seeds[32 * i: 32 * i + 32] for i in idx)
+        sel = [ops[i] for i in idx]
+        if kind == "range":
+            proofs = prove_range_batch([o[1] for o in sel], [o[2] for o in sel], [o[3] for o in sel], seeds=sd)
+        elif kind == "threshold":
+            proofs = prove_threshold_batch([o[1] for o in sel], [o[2] for o in sel], seeds=sd)
+        else:
+            proofs = prove_consistency_batch([o[1] for o in sel], seeds=sd)
+        for i, p in zip(idx, proofs):
+            out[i] = p
+    return out
 
 
 def get_batch_status(batch_id):
@@ -188,14 +287,17 @@ def clear_batch(batch_id):
 
 # ---------------------------------------------------------------- benchmark harness (advanced/mod.rs:83-172)
 def benchmark_proof_generation_numeric(proof_type, iterations):
-    if proof_type != "range":
-        if proof_type in ("equality", "threshold", "membership", "improvement", "consistency"):
-            raise NotImplementedError(_OUT_OF_SCOPE % (proof_type, "corresponding"))
+    runners = {"range": lambda: prove_range(50, 0, 100),                          # mod.rs:94-104 fixed inputs
+               "threshold": lambda: prove_threshold([10, 20, 30, 40], 50),
+               "consistency": lambda: prove_consistency([10, 20, 30, 40, 50])}
+    if proof_type not in runners:
+        if proof_type in ("equality", "membership", "improvement"):
+            raise NotImplementedError(_OUT_OF_SCOPE % (proof_type, "Groth16/STARK"))
         raise ValueError("unsupported proof type: %s" % proof_type)
     times = []
     for _ in range(iterations):
         t0 = time.perf_counter()
-        prove_range(50, 0, 100)                       # mod.rs:94
+        runners[proof_type]()
         times.append((time.perf_counter() - t0) * 1e3)
     if not times:
         raise ValueError("no successful proof generations")

@@ -363,6 +363,7 @@ int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st) {
         k_ctask<<<(C + TB - 1) / TB, TB, 0, st>>>(w.T);
         if ((rc = msm_and_encode(g.ct, C, w.T.digits, w.ct_partial, w.ct_enc, w.ct_off, w.V.out, st))) return rc;
     }
+    if (M == 0) { HIP_TRY(hipGetLastError()); return 0; }
     k_tape<<<dim3(gj.x, TAPE_SLOTS + 1), TB, 0, st>>>(w.V);
     if ((rc = msm_and_encode(g.p1, M, w.V.d1, w.partial, w.V.enc, nullptr, nullptr, st))) return rc;
     k_transcript1<<<gw, TW, 0, st>>>(w.V);
@@ -421,6 +422,96 @@ int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_
         k_any_failed<<<(uint32_t)((n + TB - 1) / TB), TB, 0, st>>>(d_status, (uint32_t)n, w.flag);
         HIP_TRY(hipMemcpyAsync(any_failed, w.flag, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Host-described jobs (threshold / consistency framings have variable-length inputs, so their job lists are built on
+// the host: pure bookkeeping, bulletproofs.rs:309-437).  The proving itself is the same device pipeline.
+struct HostJobs {
+    std::vector<uint64_t> v, proof_off, commit_off, ct_v, ct_off;
+    std::vector<uint32_t> seed_ix, proof_ix, ct_seed_ix, ct_bl_ix;
+    std::vector<int32_t> bl_plus, bl_minus;
+    std::vector<uint8_t> kind;
+    void add_job(uint64_t val, uint32_t seed, uint32_t pidx, int32_t plus, int32_t minus, uint8_t k, uint64_t poff, uint64_t coff) {
+        v.push_back(val); seed_ix.push_back(seed); proof_ix.push_back(pidx); bl_plus.push_back(plus); bl_minus.push_back(minus);
+        kind.push_back(k); proof_off.push_back(poff); commit_off.push_back(coff);
+    }
+    void add_commit(uint64_t val, uint32_t seed, uint32_t bl, uint64_t off) { ct_v.push_back(val); ct_seed_ix.push_back(seed); ct_bl_ix.push_back(bl); ct_off.push_back(off); }
+};
+
+// out: host buffer already holding every framing byte; proofs and commitments are filled in by the device
+int run_host_jobs(const HostJobs& H, const uint8_t* seeds, size_t nseeds, uint8_t* out, size_t out_bytes) {
+    const uint32_t M = (uint32_t)H.v.size(), C = (uint32_t)H.ct_v.size();
+    if (M == 0 && C == 0) return 0;
+    int rc;
+    SubBatch& sb = g.sub[0];
+    if ((rc = ensure_workspace(sb, M ? M : 1, C ? C : 1))) return rc;
+    Ws w; carve((uint8_t*)sb.ws, M ? M : 1, C ? C : 1, g.max_chunks, &w);
+    w.V.M = M; w.T.C = C;
+    hipStream_t st = g.stream;
+    uint8_t *d_seeds = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_seeds, 32 * nseeds)); HIP_TRY(hipMalloc(&d_out, out_bytes));
+    HIP_TRY(hipMemcpyAsync(d_seeds, seeds, 32 * nseeds, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_out, out, out_bytes, hipMemcpyHostToDevice, st));
+#define UP(dst, vec) do { if (!(vec).empty()) HIP_TRY(hipMemcpyAsync((void*)(dst), (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, st)); } while (0)
+    UP(w.J.v, H.v); UP(w.J.seed_ix, H.seed_ix); UP(w.J.proof_ix, H.proof_ix); UP(w.J.bl_plus, H.bl_plus); UP(w.J.bl_minus, H.bl_minus);
+    UP(w.J.kind, H.kind); UP(w.J.proof_off, H.proof_off); UP(w.J.commit_off, H.commit_off);
+    UP(w.J.ct_v, H.ct_v); UP(w.J.ct_seed_ix, H.ct_seed_ix); UP(w.J.ct_bl_ix, H.ct_bl_ix); UP(w.J.ct_off, H.ct_off);
+#undef UP
+    w.V.seeds = reinterpret_cast<const uint32_t*>(d_seeds); w.T.seeds = w.V.seeds; w.V.out = d_out;
+    rc = run_pipeline(w, M, C, st);
+    if (rc == 0) {
+        HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    (void)hipFree(d_seeds); (void)hipFree(d_out);
+    return rc;
+}
+
+void put_le_host(uint8_t* p, uint64_t x, int n) { for (int i = 0; i < n; i++) p[i] = (uint8_t)(x >> (8 * i)); }
+
+// SHA-256 (FIPS 180-4) of the commitment list, bulletproofs.rs:430-434 -- byte framing of device outputs
+void sha256_host(uint8_t out[32], const uint8_t* in, size_t len) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+        0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+        0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+        0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+        0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+        0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    std::vector<uint8_t> m(in, in + len);
+    m.push_back(0x80);
+    while (m.size() % 64 != 56) m.push_back(0);
+    for (int k = 7; k >= 0; k--) m.push_back((uint8_t)(((uint64_t)len * 8) >> (8 * k)));
+    auto ror = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+    for (size_t off = 0; off < m.size(); off += 64) {
+        uint32_t w[64];
+        for (int i = 0; i < 16; i++) w[i] = ((uint32_t)m[off + 4 * i] << 24) | ((uint32_t)m[off + 4 * i + 1] << 16) | ((uint32_t)m[off + 4 * i + 2] << 8) | m[off + 4 * i + 3];
+        for (int i = 16; i < 64; i++) {
+            const uint32_t s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], gg = h[6], hh = h[7];
+        for (int i = 0; i < 64; i++) {
+            const uint32_t t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & gg)) + K[i] + w[i];
+            const uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = gg; gg = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += gg; h[7] += hh;
+    }
+    for (int k = 0; k < 8; k++) { out[4 * k] = (uint8_t)(h[k] >> 24); out[4 * k + 1] = (uint8_t)(h[k] >> 16); out[4 * k + 2] = (uint8_t)(h[k] >> 8); out[4 * k + 3] = (uint8_t)h[k]; }
+}
+
+int fresh_seeds(std::vector<uint8_t>& buf, size_t n) {
+    buf.resize(32 * n);
+    size_t got = 0;
+    while (got < buf.size()) {
+        ssize_t r = getrandom(buf.data() + got, buf.size() - got, 0);
+        if (r <= 0) return fail(ZKP_HIP_E_RUNTIME, "getrandom failed");
+        got += (size_t)r;
     }
     return 0;
 }
@@ -494,16 +585,7 @@ int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t*
     if (!value || !min || !max || !out || !out_len || !status) return fail(ZKP_HIP_E_ARGUMENT, "null pointer argument");
     if (stride < RANGE_PROOF_BYTES) return fail(ZKP_HIP_E_ARGUMENT, "stride must be >= 1478");
     std::vector<uint8_t> fresh;
-    if (!seeds) {   // reference behaviour: fresh OS randomness per proof (bulletproofs.rs:82-87)
-        fresh.resize(32 * n);
-        size_t got = 0;
-        while (got < fresh.size()) {
-            ssize_t r = getrandom(fresh.data() + got, fresh.size() - got, 0);
-            if (r <= 0) return fail(ZKP_HIP_E_RUNTIME, "getrandom failed");
-            got += (size_t)r;
-        }
-        seeds = fresh.data();
-    }
+    if (!seeds) { int rc0 = fresh_seeds(fresh, n); if (rc0) return rc0; seeds = fresh.data(); }   // bulletproofs.rs:82-87
     std::lock_guard<std::mutex> lk(g_mu);
     int rc = init_locked(g.ready ? g.device : 0);
     if (rc) return rc;
@@ -530,6 +612,88 @@ int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t*
     (void)hipFree(d_in); (void)hipFree(d_seeds); (void)hipFree(d_out); (void)hipFree(d_len); (void)hipFree(d_status);
     if (rc) return rc;
     return any ? 1 : 0;
+}
+
+uint64_t zkp_hip_consistency_proof_bytes(uint32_t count) {
+    if (count == 0) return 0;
+    return 10 + 4 + 32ull * count + (uint64_t)(4 + RP_BYTES) * (count - 1) + 32ull * (count - 1) + 32;
+}
+
+int zkp_hip_prove_threshold_batch(uint64_t n, const uint64_t* values, const uint32_t* counts, const uint64_t* thresholds, uint32_t n_bits,
+                                  const uint8_t* seeds, uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
+    if (n_bits != 64) return fail(ZKP_HIP_E_UNSUPPORTED, "only n_bits = 64 is implemented (what prove_threshold uses)");
+    if (n == 0) return 0;
+    if (!values || !counts || !thresholds || !out || !out_len || !status) return fail(ZKP_HIP_E_ARGUMENT, "null pointer argument");
+    const uint64_t PB = 762;
+    if (stride < PB) return fail(ZKP_HIP_E_ARGUMENT, "stride must be >= 762");
+    std::vector<uint8_t> fresh;
+    if (!seeds) { int rc = fresh_seeds(fresh, n); if (rc) return rc; seeds = fresh.data(); }
+    HostJobs H; int any = 0; size_t pos = 0;
+    memset(out, 0, stride * n);
+    for (uint64_t i = 0; i < n; i++) {
+        // validation.rs:30-47 / bulletproofs.rs:314-336
+        bool ok = counts[i] > 0; uint64_t sum = 0;
+        for (uint32_t k = 0; k < counts[i] && ok; k++) { const uint64_t x = values[pos + k]; if (sum + x < sum) ok = false; sum += x; }
+        pos += counts[i];
+        if (ok && sum < thresholds[i]) ok = false;
+        status[i] = ok ? ZKP_HIP_OK : ZKP_HIP_INVALID_INPUT; out_len[i] = ok ? (uint32_t)PB : 0; any |= !ok;
+        if (!ok) continue;
+        uint8_t* o = out + i * stride; const uint64_t base = i * stride;
+        o[0] = 2; o[1] = 3; put_le_host(o + 2, 8 + 4 + 4 + RP_BYTES + 32, 4); put_le_host(o + 6, 32, 4);
+        put_le_host(o + 10, thresholds[i], 8); put_le_host(o + 18, 64, 4); put_le_host(o + 22, RP_BYTES, 4);
+        H.add_job(sum - thresholds[i], (uint32_t)i, 0, 0, -1, KIND_THRESHOLD, base + 26, base + 26 + RP_BYTES);
+        H.add_commit(sum, (uint32_t)i, 0, base + 26 + RP_BYTES + 32);
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = init_locked(g.ready ? g.device : 0);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(g.device));
+    if ((rc = run_host_jobs(H, seeds, n, out, stride * n))) return rc;
+    return any;
+}
+
+int zkp_hip_prove_consistency_batch(uint64_t n, const uint64_t* data, const uint32_t* counts, const uint8_t* seeds,
+                                    uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
+    if (n == 0) return 0;
+    if (!data || !counts || !out || !out_len || !status) return fail(ZKP_HIP_E_ARGUMENT, "null pointer argument");
+    std::vector<uint8_t> fresh;
+    if (!seeds) { int rc = fresh_seeds(fresh, n); if (rc) return rc; seeds = fresh.data(); }
+    HostJobs H; int any = 0; size_t pos = 0;
+    memset(out, 0, stride * n);
+    std::vector<size_t> starts(n);
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t k = counts[i]; const uint64_t* d = data + pos; starts[i] = pos; pos += k;
+        bool ok = k > 0;                                            // validation.rs:75-88
+        for (uint32_t j = 1; j < k && ok; j++) if (d[j - 1] > d[j]) ok = false;
+        const uint64_t need = zkp_hip_consistency_proof_bytes(k);
+        if (ok && need > stride) return fail(ZKP_HIP_E_ARGUMENT, "stride too small for a consistency proof (see zkp_hip_consistency_proof_bytes)");
+        status[i] = ok ? ZKP_HIP_OK : ZKP_HIP_INVALID_INPUT; out_len[i] = ok ? (uint32_t)need : 0; any |= !ok;
+        if (!ok) continue;
+        uint8_t* o = out + i * stride; const uint64_t base = i * stride;
+        const uint64_t body = need - 10 - 32;
+        o[0] = 2; o[1] = 6; put_le_host(o + 2, body, 4); put_le_host(o + 6, 32, 4);
+        put_le_host(o + 10, k, 4);
+        const uint64_t commits = base + 14, proofs = commits + 32ull * k, dcs = proofs + (uint64_t)(4 + RP_BYTES) * (k - 1);
+        for (uint32_t j = 0; j < k; j++) H.add_commit(d[j], (uint32_t)i, j, commits + 32ull * j);
+        for (uint32_t j = 1; j < k; j++) {
+            put_le_host(out + proofs + (uint64_t)(4 + RP_BYTES) * (j - 1), RP_BYTES, 4);
+            H.add_job(d[j] - d[j - 1], (uint32_t)i, j - 1, (int32_t)j, (int32_t)(j - 1), KIND_CONSISTENCY,
+                      proofs + (uint64_t)(4 + RP_BYTES) * (j - 1) + 4, dcs + 32ull * (j - 1));
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        int rc = init_locked(g.ready ? g.device : 0);
+        if (rc) return rc;
+        HIP_TRY(hipSetDevice(g.device));
+        if ((rc = run_host_jobs(H, seeds, n, out, stride * n))) return rc;
+    }
+    for (uint64_t i = 0; i < n; i++) {          // commitment field = SHA-256 of the commitment list (bulletproofs.rs:430-436)
+        if (status[i] != 0) continue;
+        uint8_t* o = out + i * stride;
+        sha256_host(o + out_len[i] - 32, o + 14, 32ull * counts[i]);
+    }
+    return any;
 }
 
 }  // extern "C"

@@ -153,3 +153,87 @@ def test_python_api_on_gpu(hip, oracle_c):
         z.process_batch(b)
     r = z.benchmark_proof_generation("range", 3)    # BASELINE configs[0] shape
     assert r["proof_type"] == "range" and float(r["success_rate"]) == 100.0 and float(r["proofs_per_second"]) > 0
+
+
+def _flat(lists):
+    return np.array([x for l in lists for x in l], dtype=np.uint64), np.array([len(l) for l in lists], dtype=np.uint32)
+
+
+def test_threshold_bit_exact_vs_oracle(hip, oracle_c, golden_bp):
+    """bulletproofs.rs:309-366 framing (762 bytes), incl. the benchmark harness inputs (mod.rs:96) and invalid ops."""
+    lists = [[10, 20, 30, 40], [2**64 - 1], [0], [5, 6, 7] * 20, [1, 2], [2**63, 2**63]]
+    thr = np.array([50, 2**64 - 1, 0, 100, 4, 1], dtype=np.uint64)     # op 4: sum < threshold; op 5: overflow
+    flat, counts = _flat(lists)
+    n = len(lists)
+    seeds = np.arange(32 * n, dtype=np.uint32).astype(np.uint8)
+    out, lens, st = outputs(n, 800)
+    rc = hip.zkp_hip_prove_threshold_batch(n, P(flat), P(counts), P(thr), 64, P(seeds), P(out), 800, P(lens), P(st))
+    assert rc == 1 and list(st) == [0, 0, 0, 0, 1, 1] and list(lens) == [762, 762, 762, 762, 0, 0]
+    ref = ctypes.create_string_buffer(1024)
+    ol = ctypes.c_uint32()
+    for i in range(4):
+        vals = (ctypes.c_uint64 * len(lists[i]))(*lists[i])
+        assert oracle_c.zkp_oracle_prove_threshold(vals, len(lists[i]), U64(int(thr[i])), 64, seeds[32 * i: 32 * i + 32].tobytes(), ref, 1024, ctypes.byref(ol)) == 0
+        assert out[i, :762].tobytes() == ref.raw[:762] and (out[i, 762:] == 0).all()
+        assert oracle_c.zkp_oracle_verify_threshold(out[i, :762].tobytes(), 762, U64(int(thr[i]))) == 1
+    assert (out[4] == 0).all() and (out[5] == 0).all()
+    c = golden_bp["threshold"][0]
+    flat, counts = _flat([c["values"]])
+    sd = np.frombuffer(bytes.fromhex(c["seed"]), dtype=np.uint8).copy()
+    out, lens, st = outputs(1, 762)
+    assert hip.zkp_hip_prove_threshold_batch(1, P(flat), P(counts), P(np.array([c["threshold"]], dtype=np.uint64)), 64, P(sd), P(out), 762, P(lens), P(st)) == 0
+    assert out[0].tobytes().hex() == c["proof"]
+
+
+def test_consistency_bit_exact_vs_oracle(hip, oracle_c, golden_bp):
+    """bulletproofs.rs:368-437: k commitments, k-1 range proofs with blinding differences, SHA-256 commitment digest."""
+    lists = [[10, 20, 30, 40, 50], [7], [0, 0, 2**64 - 1], [3, 2], [1, 1, 1, 1, 1, 1, 1, 1]]
+    flat, counts = _flat(lists)
+    n = len(lists)
+    stride = max(int(hip.zkp_hip_consistency_proof_bytes(len(l))) for l in lists)
+    assert int(hip.zkp_hip_consistency_proof_bytes(3)) == 1558
+    seeds = (np.arange(32 * n, dtype=np.uint32) * 7 + 1).astype(np.uint8)
+    out, lens, st = outputs(n, stride)
+    rc = hip.zkp_hip_prove_consistency_batch(n, P(flat), P(counts), P(seeds), P(out), stride, P(lens), P(st))
+    assert rc == 1 and list(st) == [0, 0, 0, 1, 0]
+    ref = ctypes.create_string_buffer(stride + 16)
+    ol = ctypes.c_uint32()
+    for i in (0, 1, 2, 4):
+        d = (ctypes.c_uint64 * len(lists[i]))(*lists[i])
+        assert oracle_c.zkp_oracle_prove_consistency(d, len(lists[i]), seeds[32 * i: 32 * i + 32].tobytes(), ref, stride + 16, ctypes.byref(ol)) == 0
+        assert lens[i] == ol.value and out[i, : lens[i]].tobytes() == ref.raw[: ol.value]
+        assert oracle_c.zkp_oracle_verify_consistency(out[i, : lens[i]].tobytes(), int(lens[i])) == 1
+    c = golden_bp["consistency"][0]
+    flat, counts = _flat([c["data"]])
+    sd = np.frombuffer(bytes.fromhex(c["seed"]), dtype=np.uint8).copy()
+    sz = len(c["proof"]) // 2
+    out, lens, st = outputs(1, sz)
+    assert hip.zkp_hip_prove_consistency_batch(1, P(flat), P(counts), P(sd), P(out), sz, P(lens), P(st)) == 0
+    assert out[0].tobytes().hex() == c["proof"]
+
+
+def test_mixed_process_batch_keeps_order(hip, oracle_c):
+    """examples/demo.rs:66-105 shape restricted to the Bulletproofs-backed variants: mixed ops, order preserved."""
+    import libzkp_amd as z
+    b = z.create_proof_batch()
+    z.batch_add_range_proof(b, 25, 18, 65)
+    z.batch_add_threshold_proof(b, [100, 200, 300], 500)
+    z.batch_add_consistency_proof(b, [10, 20, 30])
+    z.batch_add_range_proof(b, 7, 0, 10)
+    z.batch_add_threshold_proof(b, [1], 1)
+    seeds = bytes(range(160))
+    proofs = z.process_batch(b, seeds=seeds)
+    assert [p[1] for p in proofs] == [1, 3, 6, 1, 3]
+    assert oracle_c.zkp_oracle_verify_range(proofs[0], len(proofs[0]), U64(18), U64(65)) == 1
+    assert oracle_c.zkp_oracle_verify_threshold(proofs[1], len(proofs[1]), U64(500)) == 1
+    assert oracle_c.zkp_oracle_verify_consistency(proofs[2], len(proofs[2])) == 1
+    assert oracle_c.zkp_oracle_verify_range(proofs[3], len(proofs[3]), U64(0), U64(10)) == 1
+    assert oracle_c.zkp_oracle_verify_threshold(proofs[4], len(proofs[4]), U64(1)) == 1
+    # per-op seeds follow the op, not its position inside a variant bucket
+    ref = ctypes.create_string_buffer(2048)
+    ol = ctypes.c_uint32()
+    assert oracle_c.zkp_oracle_prove_range(U64(7), U64(0), U64(10), 64, seeds[96:128], ref, 2048, ctypes.byref(ol)) == 0
+    assert proofs[3] == ref.raw[: ol.value]
+    for t in ("threshold", "consistency"):
+        r = z.benchmark_proof_generation(t, 2)
+        assert r["proof_type"] == t and float(r["success_rate"]) == 100.0

@@ -43,6 +43,19 @@ def test_batch_registry_semantics():
     z.clear_batch(b)   # clearing an unknown batch is not an error (batch.rs:165-173)
 
 
+def test_threshold_and_consistency_validation_messages():
+    with pytest.raises(ValueError, match="^values cannot be empty$"):
+        z.prove_threshold([], 5)
+    with pytest.raises(ValueError, match="^integer overflow in sum calculation$"):
+        z.prove_threshold([2**64 - 1, 1], 5)
+    with pytest.raises(ValueError, match="^sum 30 is less than threshold 31$"):
+        z.prove_threshold([10, 20], 31)
+    with pytest.raises(ValueError, match="^data cannot be empty$"):
+        z.prove_consistency([])
+    with pytest.raises(ValueError, match="^data is not monotonic non-decreasing$"):
+        z.prove_consistency([1, 3, 2])
+
+
 def test_process_batch_consumes_the_batch_even_on_failure():
     b = z.create_proof_batch()
     z.batch_add_improvement_proof(b, 1, 2)
