@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--window-budget", type=int, default=0)
     ap.add_argument("--subbatches", type=int, default=0)
+    ap.add_argument("--msm-variant", type=int, default=0)
     args = ap.parse_args()
 
     import numpy as np
@@ -97,6 +98,8 @@ def main():
         L.zkp_hip_set_window_budget(args.window_budget)
     if args.subbatches:
         L.zkp_hip_set_subbatches(args.subbatches)
+    if args.msm_variant:
+        L.zkp_hip_set_msm_variant(args.msm_variant)
     _native.check(L.zkp_hip_init(local_rank), "zkp_hip_init")
 
     n = args.batch

@@ -86,6 +86,8 @@ int zkp_hip_profile_read(double* msm_ms, uint64_t* msm_launches, uint64_t* msm_p
  * so one slice's latency-bound per-proof steps can overlap another's MSM (default 1: measured slower; takes effect at the next zkp_hip_init). */
 void zkp_hip_set_window_budget(uint32_t budget);
 void zkp_hip_set_subbatches(uint32_t n);
+/* MSM kernel variant (A/B benchmarking): 1 = register-staged LDS fill, 2 = LDS-DMA double buffer (default). */
+void zkp_hip_set_msm_variant(uint32_t v);
 
 #ifdef __cplusplus
 }

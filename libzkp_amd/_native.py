@@ -13,7 +13,7 @@ RANGE_PROOF_BYTES = 1478
 EXPORTS = (
     "zkp_hip_init", "zkp_hip_shutdown", "zkp_hip_last_error", "zkp_hip_prove_range_batch",
     "zkp_hip_prove_range_batch_device", "zkp_hip_prove_threshold_batch", "zkp_hip_prove_consistency_batch",
-    "zkp_hip_consistency_proof_bytes", "zkp_hip_profile_enable", "zkp_hip_profile_read", "zkp_hip_set_window_budget", "zkp_hip_set_subbatches",
+    "zkp_hip_consistency_proof_bytes", "zkp_hip_profile_enable", "zkp_hip_profile_read", "zkp_hip_set_window_budget", "zkp_hip_set_subbatches", "zkp_hip_set_msm_variant",
 )
 
 _lib = None
@@ -68,6 +68,8 @@ def lib():
         L.zkp_hip_set_window_budget.restype = None
         L.zkp_hip_set_subbatches.argtypes = [u32]
         L.zkp_hip_set_subbatches.restype = None
+        L.zkp_hip_set_msm_variant.argtypes = [u32]
+        L.zkp_hip_set_msm_variant.restype = None
         _lib = L
     return _lib
 

@@ -73,9 +73,51 @@ __global__ void __launch_bounds__(TW) k_transcript_round(BpView V, uint32_t r) {
     Strobe s; s.base = lds + threadIdx.x; s.stride = TW; s.pos = 0; s.pos_begin = 0;
     if (job < V.M) step_transcript_round(V, r, job, s);
 }
-__global__ void __launch_bounds__(TW) k_reduce(ReduceView R) {
-    const uint32_t row = blockIdx.x * TW + threadIdx.x;
-    if (row < R.rows) reduce_encode_thread(R, blockIdx.y, row);
+// Sum of a target's chunk partials: 8 lanes cooperate on one (point, proof) -- each sums every 8th partial, then a
+// 3-level tree through LDS -- followed by k_encode (one lane per point, full waves) for the ristretto encoding.
+// (Point addition is associative and the encoding canonical, so the bytes equal reduce_encode_thread's sequential sum,
+// which the host emulation uses.)
+__global__ void __launch_bounds__(TW) k_sum(ReduceView R, uint32_t* sums) {
+    __shared__ uint32_t lds[GE_W * TW];
+    const uint32_t lane = threadIdx.x, rl = lane & 7u, grp = lane >> 3;
+    const uint32_t row = blockIdx.x * 8 + rl, target = blockIdx.y;
+    const bool active = row < R.rows;
+    const uint32_t c0 = R.target_chunk_begin[target], c1 = R.target_chunk_begin[target + 1];
+    ge acc = ge_identity();
+    bool have = false;
+    if (active) {
+        for (uint32_t c = c0 + grp; c < c1; c += 8) {
+            const ge p = ld_ge(R.partial, c, row, R.rows);
+            acc = have ? ge_add(acc, p) : p;
+            have = true;
+        }
+    }
+    for (uint32_t stride = 4; stride >= 1; stride >>= 1) {
+        if (grp >= stride && grp < 2 * stride) {
+            ZKP_UNROLL for (int k = 0; k < 10; k++) {
+                lds[k * TW + lane] = acc.X.v[k]; lds[(10 + k) * TW + lane] = acc.Y.v[k];
+                lds[(20 + k) * TW + lane] = acc.Z.v[k]; lds[(30 + k) * TW + lane] = acc.T.v[k];
+            }
+        }
+        __syncthreads();
+        if (grp < stride) {
+            ge q; const uint32_t src = lane + stride * 8;
+            ZKP_UNROLL for (int k = 0; k < 10; k++) {
+                q.X.v[k] = lds[k * TW + src]; q.Y.v[k] = lds[(10 + k) * TW + src];
+                q.Z.v[k] = lds[(20 + k) * TW + src]; q.T.v[k] = lds[(30 + k) * TW + src];
+            }
+            acc = ge_add(acc, q);
+        }
+        __syncthreads();
+    }
+    if (grp == 0 && active) st_ge(sums, target, row, R.rows, acc);
+}
+__global__ void __launch_bounds__(TW) k_encode(ReduceView R, const uint32_t* sums) {
+    const uint32_t row = blockIdx.x * TW + threadIdx.x, target = blockIdx.y;
+    if (row >= R.rows) return;
+    sc e; ge_ristretto_encode(e.v, ld_ge(sums, target, row, R.rows));
+    st_sc(R.enc, target, row, R.rows, e);
+    if (R.out_off != nullptr && target == 0) put_bytes(R.out + R.out_off[row], e.v, 8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -131,6 +173,50 @@ __global__ void __launch_bounds__(MSM_TB) k_msm(MsmView m, uint32_t ngroups, uin
     if (active) st_ge(m.partial, chunk, row, m.rows, acc);
 }
 
+// ---- variant 2: LDS-DMA.  The next (slot, window) sub-table is fetched straight into the other half of a
+// double-buffered LDS image with global_load_lds_dwordx4 (no staging VGPRs, no ds_write), while the current window's
+// point additions run; one barrier per window (after the issuing waves' vmcnt(0)) publishes it.
+__global__ void __launch_bounds__(MSM_TB) k_msm_dma(MsmView m, uint32_t ngroups, uint32_t nblocks) {
+    __shared__ uint4 lds4[2][SUBTAB_V4];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t per_xcd = (nblocks + 7) / 8;
+    const uint32_t linear = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (linear >= nblocks) return;
+    const uint32_t chunk = linear / ngroups, group = linear % ngroups;
+    const uint32_t row = group * MSM_TB + tid;
+    const bool active = row < m.rows;
+    const uint32_t s1 = m.chunk_begin[chunk + 1];
+    uint32_t s = m.chunk_begin[chunk], w = 0, cur = 0;
+    ge acc = ge_identity();
+#define ZKP_MSM_DMA(buf_, base_, win_)                                                                              \
+    do {                                                                                                            \
+        const uint4* src_ = reinterpret_cast<const uint4*>(m.table + ((size_t)(base_) * NWIN + (win_)) * SUBTAB_W);  \
+        ZKP_UNROLL for (uint32_t q_ = 0; q_ < 4; q_++) {                                                            \
+            const uint32_t first_ = q_ * MSM_TB + wave * 64u;   /* wave-uniform: 64 x 16 B = 1 KiB contiguous */    \
+            if (first_ < SUBTAB_V4)                                                                                 \
+                __builtin_amdgcn_global_load_lds(src_ + first_ + lane, &lds4[buf_][first_], 16, 0, 0);              \
+        }                                                                                                           \
+    } while (0)
+    if (s < s1) ZKP_MSM_DMA(0, m.slot_base[s], 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t dw = 0;
+    while (s < s1) {
+        const uint32_t nwin = m.slot_nwin[s];
+        uint32_t ns = s, nw = w + 1;
+        if (nw == nwin) { ns = s + 1; nw = 0; }
+        if (ns < s1) ZKP_MSM_DMA(cur ^ 1u, m.slot_base[ns], nw);   // lands while this window is being added
+        if ((w & 3u) == 0) dw = active ? m.digits[((size_t)s * 8 + (w >> 2)) * m.rows + row] : 0u;
+        const int32_t d = (int32_t)(int8_t)(dw >> (8 * (w & 3u)));
+        if (d != 0) acc = msm_accumulate_digit(acc, d, reinterpret_cast<const uint32_t*>(lds4[cur]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+        __syncthreads();                                   // every wave's pieces landed; every wave is done reading `cur`
+        s = ns; w = nw; cur ^= 1u;
+    }
+#undef ZKP_MSM_DMA
+    if (active) st_ge(m.partial, chunk, row, m.rows, acc);
+}
+
 // ================================================================================================ host
 namespace {
 
@@ -178,6 +264,7 @@ struct Ctx {
 Ctx g;
 std::mutex g_mu;
 uint32_t g_budget_request = 0;     // 0 = choose per launch
+uint32_t g_msm_variant = 2;       // 1 = register-staged LDS fill, 2 = LDS-DMA double buffer
 uint32_t g_subbatches = 1;         // >1: independent slices on separate streams (measured slower on MI355X: see DESIGN.md)
 
 int upload_layout(DevLayout& D, const MsmLayout& L) {
@@ -224,7 +311,7 @@ const DevLayout& pick_layout(const LayoutSet& S, uint32_t rows) {
         const DevLayout& D = S.t[T];
         const double blocks = (double)D.nchunks * groups;
         const double rounds = blocks <= resident ? 1.0 : blocks / resident + 0.5;   // partial last round costs about half
-        const double cost = rounds * D.max_chunk_windows * 5.6 + D.max_target_chunks * 2.6;
+        const double cost = rounds * D.max_chunk_windows * 5.6 + ((D.max_target_chunks + 7) / 8 + 3) * 2.6;
         if (cost < best_cost) { best_cost = cost; best = T; }
     }
     return S.t[best];
@@ -244,7 +331,7 @@ int init_locked(int device) {
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
     g.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_msm, MSM_TB, 0) == hipSuccess && occ > 0) g.msm_blocks_per_cu = occ;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, g_msm_variant == 1 ? k_msm : k_msm_dma, MSM_TB, 0) == hipSuccess && occ > 0) g.msm_blocks_per_cu = occ;
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&g.start_ev, hipEventDisableTiming));
     // generator tables (one-time, host)
@@ -281,7 +368,7 @@ int init_locked(int device) {
 // workspace carving ---------------------------------------------------------------------------------
 struct Ws {
     JobBuf J; BpView V; CtView T;
-    uint32_t *partial, *ct_partial, *ct_enc;
+    uint32_t *partial, *ct_partial, *ct_enc, *sums, *ct_sums;
     uint64_t* ct_off;
     int* flag;
 };
@@ -305,10 +392,12 @@ size_t carve(uint8_t* base, uint32_t M, uint32_t C, uint32_t max_chunks, Ws* w) 
     t.V.pp = (uint32_t*)take(W * 192); t.V.ab = (uint32_t*)take(W * 256); t.V.gh = (uint32_t*)take(W * 128);
     t.V.scal = (uint32_t*)take(W * SC_NUM); t.V.tstate = (uint32_t*)take(4ull * 52 * M); t.V.enc = (uint32_t*)take(W * 3);
     t.partial = (uint32_t*)take((size_t)max_chunks * GE_W * 4 * M);
+    t.sums = (uint32_t*)take((size_t)3 * GE_W * 4 * M);
     t.T.C = C; t.T.v = t.J.ct_v; t.T.seed_ix = t.J.ct_seed_ix; t.T.bl_ix = t.J.ct_bl_ix;
     t.T.digits = (uint32_t*)take((size_t)2 * 8 * 4 * C);
     t.ct_partial = (uint32_t*)take((size_t)2 * GE_W * 4 * C);
     t.ct_enc = (uint32_t*)take((size_t)8 * 4 * C);
+    t.ct_sums = (uint32_t*)take((size_t)GE_W * 4 * C);
     t.ct_off = t.J.ct_off;
     t.flag = (int*)take(256);
     if (w) *w = t;
@@ -338,21 +427,23 @@ int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32
         e0 = g.ev_pool[g.ev_used].first; e1 = g.ev_pool[g.ev_used].second; g.ev_used++;
         HIP_TRY(hipEventRecord(e0, st));
     }
-    k_msm<<<grid, MSM_TB, 0, st>>>(m, ngroups, nblocks);
+    if (g_msm_variant == 1) k_msm<<<grid, MSM_TB, 0, st>>>(m, ngroups, nblocks);
+    else k_msm_dma<<<grid, MSM_TB, 0, st>>>(m, ngroups, nblocks);
     if (g.profiling) { HIP_TRY(hipEventRecord(e1, st)); g.msm_launches++; g.msm_adds += D.adds_per_row * rows; }
     return 0;
 }
-int launch_reduce(const DevLayout& D, uint32_t rows, const uint32_t* partial, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
+int launch_reduce(const DevLayout& D, uint32_t rows, const uint32_t* partial, uint32_t* sums, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
     ReduceView R; R.rows = rows; R.ntargets = D.ntargets; R.partial = partial; R.target_chunk_begin = D.target_chunk_begin;
     R.enc = enc; R.out_off = out_off; R.out = out;
-    k_reduce<<<dim3((rows + TW - 1) / TW, D.ntargets), TW, 0, st>>>(R);
+    k_sum<<<dim3((rows + 7) / 8, D.ntargets), TW, 0, st>>>(R, sums);
+    k_encode<<<dim3((rows + TW - 1) / TW, D.ntargets), TW, 0, st>>>(R, sums);
     return 0;
 }
-int msm_and_encode(const LayoutSet& S, uint32_t rows, const uint32_t* digits, uint32_t* partial, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
+int msm_and_encode(const LayoutSet& S, uint32_t rows, const uint32_t* digits, uint32_t* partial, uint32_t* sums, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
     const DevLayout& D = pick_layout(S, rows);
     int rc = launch_msm(D, rows, digits, partial, st);
     if (rc) return rc;
-    return launch_reduce(D, rows, partial, enc, out_off, out, st);
+    return launch_reduce(D, rows, partial, sums, enc, out_off, out, st);
 }
 
 // the whole prover for M jobs + C commitment tasks already described in the workspace
@@ -361,21 +452,21 @@ int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st) {
     const dim3 gj((M + TB - 1) / TB), gw((M + TW - 1) / TW);
     if (C) {
         k_ctask<<<(C + TB - 1) / TB, TB, 0, st>>>(w.T);
-        if ((rc = msm_and_encode(g.ct, C, w.T.digits, w.ct_partial, w.ct_enc, w.ct_off, w.V.out, st))) return rc;
+        if ((rc = msm_and_encode(g.ct, C, w.T.digits, w.ct_partial, w.ct_sums, w.ct_enc, w.ct_off, w.V.out, st))) return rc;
     }
     if (M == 0) { HIP_TRY(hipGetLastError()); return 0; }
     k_tape<<<dim3(gj.x, TAPE_SLOTS + 1), TB, 0, st>>>(w.V);
-    if ((rc = msm_and_encode(g.p1, M, w.V.d1, w.partial, w.V.enc, nullptr, nullptr, st))) return rc;
+    if ((rc = msm_and_encode(g.p1, M, w.V.d1, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
     k_transcript1<<<gw, TW, 0, st>>>(w.V);
     k_poly<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V);
     k_poly_sum<<<gw, TW, 0, st>>>(w.V);
-    if ((rc = msm_and_encode(g.p2, M, w.V.d2, w.partial, w.V.enc, nullptr, nullptr, st))) return rc;
+    if ((rc = msm_and_encode(g.p2, M, w.V.d2, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
     k_transcript2<<<gw, TW, 0, st>>>(w.V);
     k_lr_init<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V);
     for (uint32_t r = 0; r < 6; r++) {
         k_round_prep<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V, r);
         k_round_sum<<<gw, TW, 0, st>>>(w.V, r);
-        if ((rc = msm_and_encode(g.rd[r], M, w.V.dr, w.partial, w.V.enc, nullptr, nullptr, st))) return rc;
+        if ((rc = msm_and_encode(g.rd[r], M, w.V.dr, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
         k_transcript_round<<<gw, TW, 0, st>>>(w.V, r);
     }
     HIP_TRY(hipGetLastError());
@@ -524,6 +615,7 @@ extern "C" {
 const char* zkp_hip_last_error(void) { return t_err.c_str(); }
 void zkp_hip_set_window_budget(uint32_t budget) { g_budget_request = budget; }
 void zkp_hip_set_subbatches(uint32_t n) { g_subbatches = n; }
+void zkp_hip_set_msm_variant(uint32_t v) { g_msm_variant = v; }
 
 int zkp_hip_init(int device) {
     std::lock_guard<std::mutex> lk(g_mu);
