@@ -31,14 +31,16 @@ ZKP_HD inline void fe_carry_wide(fe& o, uint64_t h[10]) {
     ZKP_UNROLL for (int k = 0; k < 10; k++) o.v[k] = (uint32_t)h[k];
 }
 
-// h = f * g
+// h = f * g.  Columns are accumulated in order with the previous column's carry as the initial addend of the
+// v_mad_u64_u32 chain, so the carry pass costs a shift and a mask per limb and no separate 64-bit additions.
 ZKP_HD inline fe fe_mul(const fe& f, const fe& g) {
     uint32_t g19[10], f2[10];
     ZKP_UNROLL for (int i = 0; i < 10; i++) g19[i] = 19u * g.v[i];
     ZKP_UNROLL for (int i = 1; i < 10; i += 2) f2[i] = 2u * f.v[i];
-    uint64_t h[10];
+    fe o;
+    uint64_t c = 0;
     ZKP_UNROLL for (int k = 0; k < 10; k++) {
-        uint64_t acc = 0;
+        uint64_t acc = c;
         ZKP_UNROLL for (int i = 0; i < 10; i++) {
             int j = k - i;
             const bool wrap = j < 0;
@@ -46,9 +48,14 @@ ZKP_HD inline fe fe_mul(const fe& f, const fe& g) {
             const uint32_t fi = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
             acc += (uint64_t)fi * (wrap ? g19[j] : g.v[j]);
         }
-        h[k] = acc;
+        const int bits = (k & 1) ? 25 : 26;
+        o.v[k] = (uint32_t)acc & ((1u << bits) - 1);
+        c = acc >> bits;
     }
-    fe o; fe_carry_wide(o, h); return o;
+    const uint64_t t = (uint64_t)o.v[0] + c * 19;
+    o.v[0] = (uint32_t)t & 0x3ffffffu;
+    o.v[1] += (uint32_t)(t >> 26);
+    return o;
 }
 
 // h = f^2 (55 products); f loose
