@@ -75,6 +75,26 @@ uint64_t zkp_hip_consistency_proof_bytes(uint32_t count);
 int zkp_hip_prove_consistency_batch(uint64_t n, const uint64_t* data, const uint32_t* counts, const uint8_t* seeds,
                                     uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status);
 
+/* ---- Groth16 / BN254 (equality and set-membership circuits, /root/reference/src/backend/snark.rs) ----
+ * kind: 0 = EqualityCircuit ("equality_mimc"), 1 = MembershipCircuit ("membership_mimc", 64 slots).
+ * pk = ark-serialize *uncompressed* ProvingKey<Bn254> bytes, i.e. the content of the reference's
+ * `{prefix}_pk.bin` key files (snark.rs:31-38,97-112).  Builds the fixed-base tables of every key point on the GPU. */
+int zkp_hip_groth16_load_key(int kind, const uint8_t* pk, uint64_t len);
+
+/* utils::commitment::commit_value_snark (commitment.rs:14-16; MiMC-5/110 over BN254 Fr, snark.rs:201-221): 32 bytes per value. */
+int zkp_hip_snark_commit_value_batch(uint64_t n, const uint64_t* values, uint8_t* out);
+
+/* Replaces a loop of proof::equality_proof::prove_equality(val1, val2) (equality_proof.rs:10-32 ->
+ * SnarkBackend::prove_equality_zk, snark.rs:343-374).  One 298-byte envelope (scheme 2) per op; stride >= 298. */
+int zkp_hip_prove_equality_batch(uint64_t n, const uint64_t* val1, const uint64_t* val2, const uint8_t* seeds,
+                                 uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status);
+
+/* Replaces a loop of proof::set_membership::prove_membership(value, set) (set_membership.rs:12-38 ->
+ * SnarkBackend::prove_membership_zk, snark.rs:405-452).  sets = all ops' sets concatenated, set_counts[i] <= 64.
+ * Envelope (scheme 4) = 10 + 4 + 8*len + 256 + 32 bytes; stride >= the largest. */
+int zkp_hip_prove_membership_batch(uint64_t n, const uint64_t* values, const uint64_t* sets, const uint32_t* set_counts, const uint8_t* seeds,
+                                   uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status);
+
 /* Kernel timing for the roofline line of bench.py: when enabled, every launch of the dominant kernel
  * (fixed-base MSM) is bracketed by hipEvents on its own stream. */
 void zkp_hip_profile_enable(int on);

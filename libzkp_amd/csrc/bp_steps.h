@@ -155,7 +155,8 @@ struct MsmView {
     uint32_t rows, nslots, nchunks;
     const uint32_t* table;       // generator tables
     const uint32_t* digits;      // [nslots][8][rows]
-    const uint16_t* slot_base;   // [nslots]
+    const uint16_t* slot_base;   // [nslots] which table (generator / key point) a slot uses
+    const uint16_t* slot_scalar; // [nslots] which digit row a slot reads (nullptr: row = slot)
     const uint8_t* slot_nwin;    // [nslots] number of low windows that may be non-zero
     const uint16_t* chunk_begin; // [nchunks + 1] slot ranges
     uint32_t* partial;           // [nchunks][40][rows]
@@ -165,7 +166,8 @@ ZKP_HD inline void msm_chunk_ref(const MsmView& m, uint32_t chunk, uint32_t row)
     for (uint32_t s = m.chunk_begin[chunk]; s < m.chunk_begin[chunk + 1]; s++) {
         const uint32_t base = m.slot_base[s], nwin = m.slot_nwin[s];
         for (uint32_t w = 0; w < nwin; w++) {
-            const uint32_t word = m.digits[((size_t)s * 8 + (w >> 2)) * m.rows + row];
+            const uint32_t srow = m.slot_scalar ? m.slot_scalar[s] : s;
+            const uint32_t word = m.digits[((size_t)srow * 8 + (w >> 2)) * m.rows + row];
             const int32_t d = (int32_t)(int8_t)(word >> (8 * (w & 3)));
             if (d != 0) acc = msm_accumulate_digit(acc, d, m.table + ((size_t)base * NWIN + w) * SUBTAB_W);
         }

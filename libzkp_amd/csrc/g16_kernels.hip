@@ -1,0 +1,122 @@
+// Groth16 / BN254 kernels of libzkp_hip (second translation unit; launchers declared in g16_launch.h).
+#include "g16_launch.h"
+#include "msm_kernel.h"
+
+struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b1/h/l queries)
+    static constexpr uint32_t AFF_W = 16, ACC_W = 24;
+    using Acc = g1_jac;
+    static __device__ __forceinline__ Acc identity() { return jac_infinity<fq>(); }
+    static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
+        const uint32_t* e = subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W;
+        g1_aff q; ZKP_UNROLL for (int k = 0; k < 8; k++) { q.x.v[k] = e[k]; q.y.v[k] = e[8 + k]; }
+        q.y = fp_select(d < 0, fp_neg(q.y), q.y);
+        return jac_madd(acc, q);
+    }
+    static __device__ __forceinline__ void store(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const Acc& a) { st_g1_jac(p, idx, row, rows, a); }
+    static __device__ __forceinline__ Acc load(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) { return ld_g1_jac(p, idx, row, rows); }
+    static __device__ __forceinline__ Acc add(const Acc& a, const Acc& b) { return jac_add(a, b); }
+};
+struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
+    static constexpr uint32_t AFF_W = 32, ACC_W = 48;
+    using Acc = g2_jac;
+    static __device__ __forceinline__ Acc identity() { return jac_infinity<fq2>(); }
+    static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
+        const uint32_t* e = subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W;
+        g2_aff q; ZKP_UNROLL for (int k = 0; k < 8; k++) { q.x.c0.v[k] = e[k]; q.x.c1.v[k] = e[8 + k]; q.y.c0.v[k] = e[16 + k]; q.y.c1.v[k] = e[24 + k]; }
+        q.y = f_select(d < 0, f_neg(q.y), q.y);
+        return jac_madd(acc, q);
+    }
+    static __device__ __forceinline__ void store(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const Acc& a) { st_g2_jac(p, idx, row, rows, a); }
+    static __device__ __forceinline__ Acc load(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) { return ld_g2_jac(p, idx, row, rows); }
+    static __device__ __forceinline__ Acc add(const Acc& a, const Acc& b) { return jac_add(a, b); }
+};
+
+
+// ================================================================================================ kernels
+__global__ void __launch_bounds__(TW) k_g16_witness(G16View V) {
+    const uint32_t row = blockIdx.x * TW + threadIdx.x;
+    if (row < V.rows) step_g16_witness(V, row);
+}
+__global__ void __launch_bounds__(TB) k_g16_zdigits(G16View V) {
+    const uint32_t row = blockIdx.x * TB + threadIdx.x;
+    if (row < V.rows) step_g16_zdigits(V, blockIdx.y, row);
+}
+struct DevSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
+// one workgroup = one proof; the three polynomials (a, b, c evaluations -> h) live in LDS, word-major
+__global__ void __launch_bounds__(TB) k_g16_qap(G16View V, G16Circuit C) {
+    extern __shared__ uint32_t g16_lds[];
+    G16Lds L; L.base = g16_lds; L.m = C.m;
+    g16_qap_proof(V, C, L, blockIdx.x, threadIdx.x, TB, DevSync());
+}
+__global__ void __launch_bounds__(TW) k_g16_final(G16View V, const uint32_t* sum_g1, const uint32_t* sum_g2) {
+    const uint32_t row = blockIdx.x * TW + threadIdx.x;
+    if (row < V.rows) step_g16_final(V, sum_g1, sum_g2, row);
+}
+__global__ void __launch_bounds__(TW) k_mimc_commit(const uint64_t* values, uint32_t n, const uint32_t* mimc_c, uint8_t* out) {
+    const uint32_t i = blockIdx.x * TW + threadIdx.x;
+    if (i >= n) return;
+    G16View V{}; V.mimc_c = mimc_c; V.z = nullptr;
+    const fr h = g16_mimc_chain(V, 0, fp_from_u64<FrParams>(values[i]), 0);
+    uint32_t w[8]; fp_to_raw(w, h);
+    g16_put_bytes(out + 32ull * i, w, 8);
+}
+// thread = (slot, window): entries e = 1..128 of 256^window * Base as affine points (Montgomery coordinates)
+template <class F, uint32_t AFF_W>
+__global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, uint32_t nslots, uint32_t* table) {
+    const uint32_t t = blockIdx.x * TW + threadIdx.x;
+    if (t >= nslots * NWIN) return;
+    const uint32_t slot = t / NWIN, win = t % NWIN;
+    constexpr uint32_t FW = AFF_W / 2;
+    Aff<F> base;
+    {
+        const uint32_t* b = bases + (size_t)slot * AFF_W;
+        uint32_t* bx = reinterpret_cast<uint32_t*>(&base.x); uint32_t* by = reinterpret_cast<uint32_t*>(&base.y);
+        for (uint32_t k = 0; k < FW; k++) { bx[k] = b[k]; by[k] = b[FW + k]; }
+    }
+    Jac<F> q = jac_from_aff(base);
+    for (uint32_t i = 0; i < 8 * win; i++) q = jac_dbl(q);
+    Jac<F> acc = q;
+    uint32_t* dst = table + ((size_t)slot * NWIN + win) * NENT * AFF_W;
+    for (uint32_t e = 0; e < NENT; e++) {
+        Aff<F> a; jac_to_aff(a, acc);
+        const uint32_t* ax = reinterpret_cast<const uint32_t*>(&a.x); const uint32_t* ay = reinterpret_cast<const uint32_t*>(&a.y);
+        for (uint32_t k = 0; k < FW; k++) { dst[(size_t)e * AFF_W + k] = ax[k]; dst[(size_t)e * AFF_W + FW + k] = ay[k]; }
+        acc = jac_add(acc, q);
+    }
+}
+
+
+
+template __global__ void k_msm_dma<G1Msm>(MsmView, uint32_t, uint32_t);
+template __global__ void k_msm_dma<G2Msm>(MsmView, uint32_t, uint32_t);
+template __global__ void k_sum_t<G1Msm>(ReduceView, uint32_t*);
+template __global__ void k_sum_t<G2Msm>(ReduceView, uint32_t*);
+template __global__ void k_g16_build_table<fq, 16>(const uint32_t*, uint32_t, uint32_t*);
+template __global__ void k_g16_build_table<fq2, 32>(const uint32_t*, uint32_t, uint32_t*);
+
+// ================================================================================================ launchers
+void g16_launch_witness(const G16View& V, hipStream_t st) { k_g16_witness<<<(V.rows + TW - 1) / TW, TW, 0, st>>>(V); }
+void g16_launch_zdigits(const G16View& V, hipStream_t st) { k_g16_zdigits<<<dim3((V.rows + TB - 1) / TB, V.nv), TB, 0, st>>>(V); }
+hipError_t g16_launch_qap(const G16View& V, const G16Circuit& C, hipStream_t st) {
+    const size_t lds = (size_t)3 * 8 * C.m * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_g16_qap), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    k_g16_qap<<<V.rows, TB, lds, st>>>(V, C);
+    return hipSuccess;
+}
+void g16_launch_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* sum_g2, hipStream_t st) { k_g16_final<<<(V.rows + TW - 1) / TW, TW, 0, st>>>(V, sum_g1, sum_g2); }
+void g16_launch_mimc(const uint64_t* values, uint32_t n, const uint32_t* mimc_c, uint8_t* out, hipStream_t st) { k_mimc_commit<<<(n + TW - 1) / TW, TW, 0, st>>>(values, n, mimc_c, out); }
+void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uint32_t* table, hipStream_t st) {
+    const uint32_t threads = nslots * NWIN;
+    if (!g2) k_g16_build_table<fq, 16><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table);
+    else k_g16_build_table<fq2, 32><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table);
+}
+void g16_launch_msm(bool g2, const MsmView& m, hipStream_t st) {
+    const uint32_t ngroups = (m.rows + MSM_TB - 1) / MSM_TB, nblocks = m.nchunks * ngroups, grid = ((nblocks + 7) / 8) * 8;
+    if (!g2) k_msm_dma<G1Msm><<<grid, MSM_TB, 0, st>>>(m, ngroups, nblocks);
+    else k_msm_dma<G2Msm><<<grid, MSM_TB, 0, st>>>(m, ngroups, nblocks);
+}
+void g16_launch_sum(bool g2, const ReduceView& R, uint32_t* sums, hipStream_t st) {
+    if (!g2) k_sum_t<G1Msm><<<dim3((R.rows + 7) / 8, R.ntargets), TW, 0, st>>>(R, sums);
+    else k_sum_t<G2Msm><<<dim3((R.rows + 7) / 8, R.ntargets), TW, 0, st>>>(R, sums);
+}

@@ -1,0 +1,278 @@
+// Per-thread / per-workgroup steps of the batched Groth16 prover over BN254 for libzkp's two circuits
+// (EqualityCircuit /root/reference/src/backend/snark.rs:262-291, MembershipCircuit :514-585), i.e. what
+// Groth16::<Bn254>::prove does at snark.rs:364,442 (ark-groth16 create_proof_with_reduction + LibsnarkReduction
+// witness map; restated in oracle/py/groth16.py and SURVEY.md appendix A.4).
+//
+// MI355X-first structure: one lane = one proof for witness generation and final assembly; one workgroup = one proof
+// for the QAP division (all seven size-m NTTs of a proof stay in LDS); every MSM is a fixed-base, lane = proof,
+// LDS-streamed-window kernel over the proving key's points (same kernel template as the Bulletproofs path).
+#pragma once
+#include "bn254_g.h"
+#include "keccak.h"
+#include "sc25519.h"
+
+namespace zkp {
+
+constexpr uint32_t MIMC_ROUNDS = 110, G16_MAX_SET = 64;
+constexpr uint32_t G16_TAPE_IDX = 0x47313600u;
+enum { G16_EQUALITY = 0, G16_MEMBERSHIP = 1 };
+
+ZKP_HD inline fr ld_fr(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) {
+    fr r; const uint32_t* q = p + (size_t)idx * 8 * rows + row;
+    ZKP_UNROLL for (int k = 0; k < 8; k++) r.v[k] = q[(size_t)k * rows];
+    return r;
+}
+ZKP_HD inline void st_fr(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const fr& s) {
+    uint32_t* q = p + (size_t)idx * 8 * rows + row;
+    ZKP_UNROLL for (int k = 0; k < 8; k++) q[(size_t)k * rows] = s.v[k];
+}
+ZKP_HD inline fr ld_fr_c(const uint32_t* p, uint32_t idx) { fr r; ZKP_UNROLL for (int k = 0; k < 8; k++) r.v[k] = p[(size_t)idx * 8 + k]; return r; }
+ZKP_HD inline void g16_put_bytes(uint8_t* dst, const uint32_t* w, int nwords) {
+    for (int i = 0; i < nwords; i++) { dst[4 * i] = (uint8_t)w[i]; dst[4 * i + 1] = (uint8_t)(w[i] >> 8); dst[4 * i + 2] = (uint8_t)(w[i] >> 16); dst[4 * i + 3] = (uint8_t)(w[i] >> 24); }
+}
+// packed signed radix-256 digits of a Montgomery-form Fr element (canonical value < r < 2^254: 32 windows)
+ZKP_HD inline void st_fr_digits(uint32_t* d, uint32_t idx, uint32_t row, uint32_t rows, const fr& x) {
+    sc raw; fp_to_raw(raw.v, x);
+    sc pk; sc_recode_signed256(pk.v, raw);
+    uint32_t* q = d + (size_t)idx * 8 * rows + row;
+    ZKP_UNROLL for (int k = 0; k < 8; k++) q[(size_t)k * rows] = pk.v[k];
+}
+
+struct G16View {
+    uint32_t rows, kind;
+    uint32_t n_inst, n_wit, nv, m;            // circuit shape; m = domain size
+    // inputs
+    const uint64_t* value;                    // [rows] the committed value (a for equality, value for membership)
+    const uint64_t* set_vals;                 // membership: [rows][64] padded set, else null
+    const uint32_t* set_len;                  // membership: [rows]
+    const uint32_t* seeds;                    // [rows][8]
+    const uint32_t* mimc_c;                   // [110][8] round constants (Montgomery Fr)
+    // workspace
+    uint32_t* z;                              // [nv][8][rows] full assignment (instance block first), Montgomery Fr
+    uint32_t* sdig;                           // [nscalars][8][rows] packed digits: z_k (nv), h_i (m-1), r, s, -rs, one
+    uint32_t* rs;                             // [2][8][rows] raw canonical r, s (for the variable-base part of C)
+    // output
+    uint8_t* out; uint64_t stride;            // envelope per row
+};
+ZKP_HD inline uint32_t g16_sc_h(const G16View& V) { return V.nv; }
+ZKP_HD inline uint32_t g16_sc_r(const G16View& V) { return V.nv + V.m - 1; }
+ZKP_HD inline uint32_t g16_sc_s(const G16View& V) { return V.nv + V.m; }
+ZKP_HD inline uint32_t g16_sc_nrs(const G16View& V) { return V.nv + V.m + 1; }
+ZKP_HD inline uint32_t g16_sc_one(const G16View& V) { return V.nv + V.m + 2; }
+ZKP_HD inline uint32_t g16_nscalars(uint32_t nv, uint32_t m) { return nv + m + 3; }
+
+// MiMC-5 chain (snark.rs:201-211) writing the circuit's intermediate witnesses t^2, t^4, t^5 (snark.rs:232-247).
+// wit0 = index in z of the first MiMC witness.  Returns the hash.
+ZKP_HD inline fr g16_mimc_chain(const G16View& V, uint32_t row, fr x, uint32_t wit0) {
+    for (uint32_t i = 0; i < MIMC_ROUNDS; i++) {
+        const fr t = fp_add(x, ld_fr_c(V.mimc_c, i));
+        const fr t2 = fp_sq(t), t4 = fp_sq(t2);
+        x = fp_mul(t4, t);
+        if (V.z) { st_fr(V.z, wit0 + 3 * i, row, V.rows, t2); st_fr(V.z, wit0 + 3 * i + 1, row, V.rows, t4); st_fr(V.z, wit0 + 3 * i + 2, row, V.rows, x); }
+    }
+    return x;
+}
+
+// thread = proof.  Fills z, the envelope header + commitment, r/s and their digits.
+ZKP_HD inline void step_g16_witness(const G16View& V, uint32_t row) {
+    const uint32_t rows = V.rows;
+    const uint64_t val = V.value[row];
+    const fr one = fp_one<FrParams>(), zero = fp_zero<FrParams>();
+    const fr v = fp_from_u64<FrParams>(val);
+    uint8_t* o = V.out + (uint64_t)row * V.stride;
+    st_fr(V.z, 0, row, rows, one);
+    fr h;
+    uint32_t proof_len = 256;
+    if (V.kind == G16_EQUALITY) {
+        // instance: [1, commitment]; witness: a, b, MiMC(3 x 110)          (snark.rs:262-291)
+        st_fr(V.z, 2, row, rows, v); st_fr(V.z, 3, row, rows, v);
+        h = g16_mimc_chain(V, row, v, 4);
+        st_fr(V.z, 1, row, rows, h);
+        o[0] = 2; o[1] = 2;
+    } else {
+        // instance: [1, commitment, set[64], is_real[64]]; witness: value, MiMC, sel[64], sel*(1-is_real)[64], sel*(value-set)[64]
+        const uint32_t len = V.set_len[row];
+        const uint64_t* sv = V.set_vals + (size_t)row * G16_MAX_SET;
+        const uint32_t w0 = V.n_inst;                       // first witness index
+        st_fr(V.z, w0, row, rows, v);
+        h = g16_mimc_chain(V, row, v, w0 + 1);
+        st_fr(V.z, 1, row, rows, h);
+        uint32_t pos = 0xffffffffu;
+        for (uint32_t i = 0; i < len; i++) if (pos == 0xffffffffu && sv[i] == val) pos = i;     // set.iter().position (snark.rs:415-418)
+        const uint32_t sel0 = w0 + 1 + 3 * MIMC_ROUNDS;
+        for (uint32_t i = 0; i < G16_MAX_SET; i++) {
+            const bool real = i < len;
+            const fr si = fp_from_u64<FrParams>(real ? sv[i] : 0);
+            st_fr(V.z, 2 + i, row, rows, si);
+            st_fr(V.z, 2 + G16_MAX_SET + i, row, rows, real ? one : zero);
+            const bool sel = i == pos;
+            st_fr(V.z, sel0 + i, row, rows, sel ? one : zero);
+            st_fr(V.z, sel0 + G16_MAX_SET + i, row, rows, (sel && !real) ? one : zero);        // sel * (1 - is_real)
+            st_fr(V.z, sel0 + 2 * G16_MAX_SET + i, row, rows, sel ? fp_sub(v, si) : zero);       // sel * (value - set_i)
+        }
+        o[0] = 2; o[1] = 4;
+        proof_len = 4 + 8 * len + 256;
+        uint8_t* pl = o + 10;
+        pl[0] = (uint8_t)len; pl[1] = (uint8_t)(len >> 8); pl[2] = (uint8_t)(len >> 16); pl[3] = (uint8_t)(len >> 24);
+        for (uint32_t i = 0; i < len; i++) for (int k = 0; k < 8; k++) pl[4 + 8 * i + k] = (uint8_t)(sv[i] >> (8 * k));
+    }
+    for (int k = 0; k < 4; k++) { o[2 + k] = (uint8_t)(proof_len >> (8 * k)); o[6 + k] = (uint8_t)(32u >> (8 * k)); }
+    uint32_t hraw[8]; fp_to_raw(hraw, h);
+    g16_put_bytes(o + 10 + proof_len, hraw, 8);          // commitment = fr_to_commitment(mimc) (commitment.rs:14-16)
+    // prover randomness
+    uint32_t seed[8]; ZKP_UNROLL for (int k = 0; k < 8; k++) seed[k] = V.seeds[(size_t)row * 8 + k];
+    uint32_t w[16];
+    tape_draw64(w, seed, G16_TAPE_IDX, 0); const fr r = fp_from_wide<FrParams>(w);
+    tape_draw64(w, seed, G16_TAPE_IDX, 1); const fr s = fp_from_wide<FrParams>(w);
+    st_fr_digits(V.sdig, g16_sc_r(V), row, rows, r);
+    st_fr_digits(V.sdig, g16_sc_s(V), row, rows, s);
+    st_fr_digits(V.sdig, g16_sc_nrs(V), row, rows, fp_neg(fp_mul(r, s)));
+    uint32_t* q = V.sdig + (size_t)g16_sc_one(V) * 8 * rows + row;
+    q[0] = 1u; for (int k = 1; k < 8; k++) q[(size_t)k * rows] = 0u;
+    fr rr, sr; fp_to_raw(rr.v, r); fp_to_raw(sr.v, s);
+    st_fr(V.rs, 0, row, rows, rr); st_fr(V.rs, 1, row, rows, sr);
+}
+// thread = (variable k, proof): digits of z_k
+ZKP_HD inline void step_g16_zdigits(const G16View& V, uint32_t k, uint32_t row) {
+    st_fr_digits(V.sdig, k, row, V.rows, ld_fr(V.z, k, row, V.rows));
+}
+
+// ---- R1CS matrices in CSR form (coefficients in Montgomery Fr) and the domain tables, all read-only
+struct G16Circuit {
+    uint32_t n_rows, m, logm;
+    const uint32_t *a_ptr, *a_col, *a_coef, *b_ptr, *b_col, *b_coef, *c_ptr, *c_col, *c_coef;
+    const uint32_t *tw, *tw_inv;         // [m/2][8]  w^j, w^-j
+    const uint32_t *coset, *coset_inv;   // [m][8]    g^i / m ,  g^-i / m
+    const uint32_t* zinv;                // [8]       1 / (g^m - 1)
+};
+ZKP_HD inline fr g16_row_dot(const uint32_t* ptr, const uint32_t* col, const uint32_t* coef, uint32_t r, const uint32_t* z, uint32_t row, uint32_t rows) {
+    fr acc = fp_zero<FrParams>();
+    for (uint32_t e = ptr[r]; e < ptr[r + 1]; e++) acc = fp_add(acc, fp_mul(ld_fr_c(coef, e), ld_fr(z, col[e], row, rows)));
+    return acc;
+}
+ZKP_HD inline uint32_t g16_bitrev(uint32_t x, uint32_t bits) {
+    uint32_t r = 0; for (uint32_t i = 0; i < bits; i++) { r = (r << 1) | (x & 1u); x >>= 1; } return r;
+}
+
+// The QAP witness map of ONE proof on a word-major image x[poly][word][element] (LDS on the GPU).  `nthreads` lanes
+// cooperate; `sync` is the workgroup barrier.  Reference semantic: LibsnarkReduction::witness_map_from_matrices.
+struct G16Lds {
+    uint32_t* base; uint32_t m;
+    ZKP_HD fr ld(uint32_t poly, uint32_t e) const { fr r; ZKP_UNROLL for (int k = 0; k < 8; k++) r.v[k] = base[((size_t)poly * 8 + k) * m + e]; return r; }
+    ZKP_HD void st(uint32_t poly, uint32_t e, const fr& v) const { ZKP_UNROLL for (int k = 0; k < 8; k++) base[((size_t)poly * 8 + k) * m + e] = v.v[k]; }
+};
+// phase functions; each is called by every lane `tid` of the workgroup with a barrier between phases
+ZKP_HD inline void g16_qap_load(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t row, uint32_t tid, uint32_t nthreads) {
+    const uint32_t nc = C.n_rows;
+    for (uint32_t j = tid; j < C.m; j += nthreads) {
+        fr a = fp_zero<FrParams>(), b = a, c = a;
+        if (j < nc) {
+            a = g16_row_dot(C.a_ptr, C.a_col, C.a_coef, j, V.z, row, V.rows);
+            b = g16_row_dot(C.b_ptr, C.b_col, C.b_coef, j, V.z, row, V.rows);
+            c = g16_row_dot(C.c_ptr, C.c_col, C.c_coef, j, V.z, row, V.rows);
+        } else if (j < nc + V.n_inst) {
+            a = ld_fr(V.z, j - nc, row, V.rows);                    // a[n_constraints + i] = z_i (instance)
+        }
+        const uint32_t p = g16_bitrev(j, C.logm);                   // DIT inverse transform wants bit-reversed input
+        L.st(0, p, a); L.st(1, p, b); L.st(2, p, c);
+    }
+}
+// one DIT stage (len = 2*half) on `npoly` polynomials with twiddle table tw (stride m/len)
+ZKP_HD inline void g16_dit_stage(const G16Circuit& C, const G16Lds& L, const uint32_t* tw, uint32_t half, uint32_t npoly, uint32_t tid, uint32_t nthreads) {
+    const uint32_t len = 2 * half, tstride = C.m / len;
+    for (uint32_t k = tid; k < C.m / 2; k += nthreads) {
+        const uint32_t grp = k / half, j = k % half, i0 = grp * len + j, i1 = i0 + half;
+        const fr w = ld_fr_c(tw, j * tstride);
+        for (uint32_t p = 0; p < npoly; p++) {
+            const fr u = L.ld(p, i0), v = fp_mul(L.ld(p, i1), w);
+            L.st(p, i0, fp_add(u, v)); L.st(p, i1, fp_sub(u, v));
+        }
+    }
+}
+ZKP_HD inline void g16_dif_stage(const G16Circuit& C, const G16Lds& L, const uint32_t* tw, uint32_t half, uint32_t npoly, uint32_t tid, uint32_t nthreads) {
+    const uint32_t len = 2 * half, tstride = C.m / len;
+    for (uint32_t k = tid; k < C.m / 2; k += nthreads) {
+        const uint32_t grp = k / half, j = k % half, i0 = grp * len + j, i1 = i0 + half;
+        const fr w = ld_fr_c(tw, j * tstride);
+        for (uint32_t p = 0; p < npoly; p++) {
+            const fr u = L.ld(p, i0), v = L.ld(p, i1);
+            L.st(p, i0, fp_add(u, v)); L.st(p, i1, fp_mul(fp_sub(u, v), w));
+        }
+    }
+}
+ZKP_HD inline void g16_scale(const G16Circuit& C, const G16Lds& L, const uint32_t* tab, uint32_t npoly, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid; i < C.m; i += nthreads) {
+        const fr f = ld_fr_c(tab, i);
+        for (uint32_t p = 0; p < npoly; p++) L.st(p, i, fp_mul(L.ld(p, i), f));
+    }
+}
+ZKP_HD inline void g16_pointwise(const G16Circuit& C, const G16Lds& L, uint32_t tid, uint32_t nthreads) {
+    const fr zinv = ld_fr_c(C.zinv, 0);
+    for (uint32_t i = tid; i < C.m; i += nthreads)
+        L.st(0, i, fp_mul(fp_sub(fp_mul(L.ld(0, i), L.ld(1, i)), L.ld(2, i)), zinv));
+}
+ZKP_HD inline void g16_store_h(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t row, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid; i + 1 < C.m; i += nthreads)
+        st_fr_digits(V.sdig, g16_sc_h(V) + i, row, V.rows, fp_mul(L.ld(0, i), ld_fr_c(C.coset_inv, i)));
+}
+// the whole witness map, written so that host emulation (nthreads = 1, sync = no-op) and the kernel share it
+template <class Sync>
+ZKP_HD inline void g16_qap_proof(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t row, uint32_t tid, uint32_t nthreads, Sync sync) {
+    g16_qap_load(V, C, L, row, tid, nthreads); sync();
+    for (uint32_t half = 1; half < C.m; half <<= 1) { g16_dit_stage(C, L, C.tw_inv, half, 3, tid, nthreads); sync(); }   // iFFT (x m)
+    g16_scale(C, L, C.coset, 3, tid, nthreads); sync();                                                                // /m and coset shift g^i
+    for (uint32_t half = C.m / 2; half >= 1; half >>= 1) { g16_dif_stage(C, L, C.tw, half, 3, tid, nthreads); sync(); } // coset FFT (bit-reversed out)
+    g16_pointwise(C, L, tid, nthreads); sync();                                                                        // (a*b - c) / Z(g w^j)
+    for (uint32_t half = 1; half < C.m; half <<= 1) { g16_dit_stage(C, L, C.tw_inv, half, 1, tid, nthreads); sync(); }   // coset iFFT
+    g16_store_h(V, C, L, row, tid, nthreads);                                                                          // /m, g^-i, digits
+}
+
+// ---- final assembly.  thread = proof.  sums: [4 targets][words][rows] Jacobian sums A (G1), B1 (G1), Cp (G1), B2 (G2)
+struct G16Final {
+    const uint32_t* sum_g1;      // [3][24][rows]
+    const uint32_t* sum_g2;      // [1][48][rows]
+    const uint32_t* delta_unused;
+};
+ZKP_HD inline g1_jac ld_g1_jac(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) {
+    g1_jac r; const uint32_t* q = p + (size_t)idx * 24 * rows + row;
+    ZKP_UNROLL for (int k = 0; k < 8; k++) { r.X.v[k] = q[(size_t)k * rows]; r.Y.v[k] = q[(size_t)(8 + k) * rows]; r.Z.v[k] = q[(size_t)(16 + k) * rows]; }
+    return r;
+}
+ZKP_HD inline void st_g1_jac(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const g1_jac& g) {
+    uint32_t* q = p + (size_t)idx * 24 * rows + row;
+    ZKP_UNROLL for (int k = 0; k < 8; k++) { q[(size_t)k * rows] = g.X.v[k]; q[(size_t)(8 + k) * rows] = g.Y.v[k]; q[(size_t)(16 + k) * rows] = g.Z.v[k]; }
+}
+ZKP_HD inline g2_jac ld_g2_jac(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) {
+    g2_jac r; const uint32_t* q = p + (size_t)idx * 48 * rows + row;
+    ZKP_UNROLL for (int k = 0; k < 8; k++) {
+        r.X.c0.v[k] = q[(size_t)k * rows]; r.X.c1.v[k] = q[(size_t)(8 + k) * rows];
+        r.Y.c0.v[k] = q[(size_t)(16 + k) * rows]; r.Y.c1.v[k] = q[(size_t)(24 + k) * rows];
+        r.Z.c0.v[k] = q[(size_t)(32 + k) * rows]; r.Z.c1.v[k] = q[(size_t)(40 + k) * rows];
+    }
+    return r;
+}
+ZKP_HD inline void st_g2_jac(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const g2_jac& g) {
+    uint32_t* q = p + (size_t)idx * 48 * rows + row;
+    ZKP_UNROLL for (int k = 0; k < 8; k++) {
+        q[(size_t)k * rows] = g.X.c0.v[k]; q[(size_t)(8 + k) * rows] = g.X.c1.v[k];
+        q[(size_t)(16 + k) * rows] = g.Y.c0.v[k]; q[(size_t)(24 + k) * rows] = g.Y.c1.v[k];
+        q[(size_t)(32 + k) * rows] = g.Z.c0.v[k]; q[(size_t)(40 + k) * rows] = g.Z.c1.v[k];
+    }
+}
+// C = Cp + s*A + r*B1 (Cp already contains l_aux, h and -rs*delta); proof = A || B2 || C  (snark.rs:369-373)
+ZKP_HD inline void step_g16_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* sum_g2, uint32_t row) {
+    const uint32_t rows = V.rows;
+    const g1_jac A = ld_g1_jac(sum_g1, 0, row, rows), B1 = ld_g1_jac(sum_g1, 1, row, rows), Cp = ld_g1_jac(sum_g1, 2, row, rows);
+    const g2_jac B2 = ld_g2_jac(sum_g2, 0, row, rows);
+    const fr rr = ld_fr(V.rs, 0, row, rows), sr = ld_fr(V.rs, 1, row, rows);
+    const g1_jac Cc = jac_add(jac_add(Cp, jac_mul_raw(A, sr.v)), jac_mul_raw(B1, rr.v));
+    uint8_t* o = V.out + (uint64_t)row * V.stride;
+    uint32_t plen = 0; for (int k = 0; k < 4; k++) plen |= (uint32_t)o[2 + k] << (8 * k);
+    uint8_t* pr = o + 10 + plen - 256;
+    uint32_t w1[16], w2[32];
+    g1_serialize(w1, A); g16_put_bytes(pr, w1, 16);
+    g2_serialize(w2, B2); g16_put_bytes(pr + 64, w2, 32);
+    g1_serialize(w1, Cc); g16_put_bytes(pr + 192, w1, 16);
+}
+
+}  // namespace zkp

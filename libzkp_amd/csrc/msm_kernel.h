@@ -1,0 +1,92 @@
+// Point-type-generic fixed-base MSM and partial-sum kernels (shared by the Bulletproofs and Groth16 translation units).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "bp_steps.h"
+
+using namespace zkp;
+static constexpr int MSM_TB = 256;   // lanes (= proofs) per MSM workgroup
+static constexpr int TW = 64;        // one wave per block for per-proof serial steps
+static constexpr int TB = 256;       // threads per block for (i, proof) grids
+
+// ---- variant 2 (default): LDS-DMA, templated on the point type.  The next (slot, window) sub-table is fetched
+// straight into the other half of a double-buffered LDS image with global_load_lds_dwordx4 (no staging VGPRs, no
+// ds_write) while the current window's point additions run; one barrier per window (after the issuing waves'
+// vmcnt(0)) publishes it.
+template <class T>
+__global__ void __launch_bounds__(MSM_TB) k_msm_dma(MsmView m, uint32_t ngroups, uint32_t nblocks) {
+#if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins: keep the host-side stub instantiation empty
+    constexpr uint32_t SUB_W = NENT * T::AFF_W, SUB_V4 = SUB_W / 4;
+    __shared__ uint4 lds4[2][SUB_V4];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t per_xcd = (nblocks + 7) / 8;
+    const uint32_t linear = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (linear >= nblocks) return;
+    const uint32_t chunk = linear / ngroups, group = linear % ngroups;
+    const uint32_t row = group * MSM_TB + tid;
+    const bool active = row < m.rows;
+    const uint32_t s1 = m.chunk_begin[chunk + 1];
+    uint32_t s = m.chunk_begin[chunk], w = 0, cur = 0;
+    typename T::Acc acc = T::identity();
+#define ZKP_MSM_DMA(buf_, base_, win_)                                                                              \
+    do {                                                                                                            \
+        const uint4* src_ = reinterpret_cast<const uint4*>(m.table + ((size_t)(base_) * NWIN + (win_)) * SUB_W);     \
+        ZKP_UNROLL for (uint32_t q_ = 0; q_ < (SUB_V4 + MSM_TB - 1) / MSM_TB; q_++) {                               \
+            const uint32_t first_ = q_ * MSM_TB + wave * 64u;   /* wave-uniform: 64 x 16 B = 1 KiB contiguous */    \
+            if (first_ < SUB_V4)                                                                                    \
+                __builtin_amdgcn_global_load_lds(src_ + first_ + lane, &lds4[buf_][first_], 16, 0, 0);              \
+        }                                                                                                           \
+    } while (0)
+    if (s < s1) ZKP_MSM_DMA(0, m.slot_base[s], 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t dw = 0;
+    while (s < s1) {
+        const uint32_t nwin = m.slot_nwin[s];
+        uint32_t ns = s, nw = w + 1;
+        if (nw == nwin) { ns = s + 1; nw = 0; }
+        if (ns < s1) ZKP_MSM_DMA(cur ^ 1u, m.slot_base[ns], nw);   // lands while this window is being added
+        if ((w & 3u) == 0) {
+            const uint32_t srow = m.slot_scalar ? m.slot_scalar[s] : s;
+            dw = active ? m.digits[((size_t)srow * 8 + (w >> 2)) * m.rows + row] : 0u;
+        }
+        const int32_t d = (int32_t)(int8_t)(dw >> (8 * (w & 3u)));
+        if (d != 0) acc = T::accumulate(acc, d, reinterpret_cast<const uint32_t*>(lds4[cur]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+        __syncthreads();                                   // every wave's pieces landed; every wave is done reading `cur`
+        s = ns; w = nw; cur ^= 1u;
+    }
+#undef ZKP_MSM_DMA
+    if (active) T::store(m.partial, chunk, row, m.rows, acc);
+#else
+    (void)m; (void)ngroups; (void)nblocks;
+#endif
+}
+
+// 8 lanes cooperate on one (target, row): each sums every 8th chunk partial, then a 3-level tree through LDS.
+template <class T>
+__global__ void __launch_bounds__(TW) k_sum_t(ReduceView R, uint32_t* sums) {
+    __shared__ uint32_t lds[T::ACC_W * TW];
+    const uint32_t lane = threadIdx.x, rl = lane & 7u, grp = lane >> 3;
+    const uint32_t row = blockIdx.x * 8 + rl, target = blockIdx.y;
+    const bool active = row < R.rows;
+    const uint32_t c0 = R.target_chunk_begin[target], c1 = R.target_chunk_begin[target + 1];
+    typename T::Acc acc = T::identity();
+    bool have = false;
+    if (active) {
+        for (uint32_t c = c0 + grp; c < c1; c += 8) {
+            const typename T::Acc p = T::load(R.partial, c, row, R.rows);
+            acc = have ? T::add(acc, p) : p;
+            have = true;
+        }
+    }
+    uint32_t* mine = lds + lane;     // word k of this lane at mine[k * TW]
+    for (uint32_t stride = 4; stride >= 1; stride >>= 1) {
+        if (grp >= stride && grp < 2 * stride) T::store(lds, 0, lane, TW, acc);
+        __syncthreads();
+        if (grp < stride) acc = T::add(acc, T::load(lds, 0, lane + stride * 8, TW));
+        __syncthreads();
+    }
+    (void)mine;
+    if (grp == 0 && active) T::store(sums, target, row, R.rows, acc);
+}
+

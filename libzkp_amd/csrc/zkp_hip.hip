@@ -4,6 +4,9 @@
 // 256 proofs and the per-lane table gathers hit LDS instead of HBM/L2.
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <map>
+#include <array>
+#include <type_traits>
 #include <atomic>
 #include <thread>
 #include <cstring>
@@ -13,13 +16,12 @@
 #include <cstdlib>
 #include <sys/random.h>
 #include "bp_layout.h"
+#include "g16_steps.h"
+#include "msm_kernel.h"
+#include "g16_launch.h"
 #include "../../include/libzkp_hip.h"
 
-using namespace zkp;
-
 // ================================================================================================ kernels
-static constexpr int TB = 256;   // threads per block for (i, job) grids
-static constexpr int TW = 64;    // one wave per block for per-job serial steps (STROBE image in LDS)
 
 __global__ void __launch_bounds__(TB) k_build_range(JobBuf J, uint32_t n, const uint64_t* value, const uint64_t* mn, const uint64_t* mx,
                                                     uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
@@ -77,41 +79,6 @@ __global__ void __launch_bounds__(TW) k_transcript_round(BpView V, uint32_t r) {
 // 3-level tree through LDS -- followed by k_encode (one lane per point, full waves) for the ristretto encoding.
 // (Point addition is associative and the encoding canonical, so the bytes equal reduce_encode_thread's sequential sum,
 // which the host emulation uses.)
-__global__ void __launch_bounds__(TW) k_sum(ReduceView R, uint32_t* sums) {
-    __shared__ uint32_t lds[GE_W * TW];
-    const uint32_t lane = threadIdx.x, rl = lane & 7u, grp = lane >> 3;
-    const uint32_t row = blockIdx.x * 8 + rl, target = blockIdx.y;
-    const bool active = row < R.rows;
-    const uint32_t c0 = R.target_chunk_begin[target], c1 = R.target_chunk_begin[target + 1];
-    ge acc = ge_identity();
-    bool have = false;
-    if (active) {
-        for (uint32_t c = c0 + grp; c < c1; c += 8) {
-            const ge p = ld_ge(R.partial, c, row, R.rows);
-            acc = have ? ge_add(acc, p) : p;
-            have = true;
-        }
-    }
-    for (uint32_t stride = 4; stride >= 1; stride >>= 1) {
-        if (grp >= stride && grp < 2 * stride) {
-            ZKP_UNROLL for (int k = 0; k < 10; k++) {
-                lds[k * TW + lane] = acc.X.v[k]; lds[(10 + k) * TW + lane] = acc.Y.v[k];
-                lds[(20 + k) * TW + lane] = acc.Z.v[k]; lds[(30 + k) * TW + lane] = acc.T.v[k];
-            }
-        }
-        __syncthreads();
-        if (grp < stride) {
-            ge q; const uint32_t src = lane + stride * 8;
-            ZKP_UNROLL for (int k = 0; k < 10; k++) {
-                q.X.v[k] = lds[k * TW + src]; q.Y.v[k] = lds[(10 + k) * TW + src];
-                q.Z.v[k] = lds[(20 + k) * TW + src]; q.T.v[k] = lds[(30 + k) * TW + src];
-            }
-            acc = ge_add(acc, q);
-        }
-        __syncthreads();
-    }
-    if (grp == 0 && active) st_ge(sums, target, row, R.rows, acc);
-}
 __global__ void __launch_bounds__(TW) k_encode(ReduceView R, const uint32_t* sums) {
     const uint32_t row = blockIdx.x * TW + threadIdx.x, target = blockIdx.y;
     if (row >= R.rows) return;
@@ -129,7 +96,6 @@ __global__ void __launch_bounds__(TW) k_encode(ReduceView R, const uint32_t* sum
 //           point addition) and gathered per lane by its own signed digit.
 //   XCD   : workgroups that share a chunk (hence the same sub-tables) are mapped onto the same XCD so
 //           the sub-table stays in that XCD's 4 MB L2 (blocks b and b+8 share an XCD).
-static constexpr int MSM_TB = 256;
 static constexpr uint32_t SUBTAB_V4 = SUBTAB_W / 4;   // 960 x 16 bytes
 static_assert(SUBTAB_V4 > 3 * 256 && SUBTAB_V4 <= 4 * 256, "prefetch pattern assumes 768 < 960 <= 1024");
 
@@ -173,49 +139,18 @@ __global__ void __launch_bounds__(MSM_TB) k_msm(MsmView m, uint32_t ngroups, uin
     if (active) st_ge(m.partial, chunk, row, m.rows, acc);
 }
 
-// ---- variant 2: LDS-DMA.  The next (slot, window) sub-table is fetched straight into the other half of a
-// double-buffered LDS image with global_load_lds_dwordx4 (no staging VGPRs, no ds_write), while the current window's
-// point additions run; one barrier per window (after the issuing waves' vmcnt(0)) publishes it.
-__global__ void __launch_bounds__(MSM_TB) k_msm_dma(MsmView m, uint32_t ngroups, uint32_t nblocks) {
-    __shared__ uint4 lds4[2][SUBTAB_V4];
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint32_t per_xcd = (nblocks + 7) / 8;
-    const uint32_t linear = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if (linear >= nblocks) return;
-    const uint32_t chunk = linear / ngroups, group = linear % ngroups;
-    const uint32_t row = group * MSM_TB + tid;
-    const bool active = row < m.rows;
-    const uint32_t s1 = m.chunk_begin[chunk + 1];
-    uint32_t s = m.chunk_begin[chunk], w = 0, cur = 0;
-    ge acc = ge_identity();
-#define ZKP_MSM_DMA(buf_, base_, win_)                                                                              \
-    do {                                                                                                            \
-        const uint4* src_ = reinterpret_cast<const uint4*>(m.table + ((size_t)(base_) * NWIN + (win_)) * SUBTAB_W);  \
-        ZKP_UNROLL for (uint32_t q_ = 0; q_ < 4; q_++) {                                                            \
-            const uint32_t first_ = q_ * MSM_TB + wave * 64u;   /* wave-uniform: 64 x 16 B = 1 KiB contiguous */    \
-            if (first_ < SUBTAB_V4)                                                                                 \
-                __builtin_amdgcn_global_load_lds(src_ + first_ + lane, &lds4[buf_][first_], 16, 0, 0);              \
-        }                                                                                                           \
-    } while (0)
-    if (s < s1) ZKP_MSM_DMA(0, m.slot_base[s], 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    uint32_t dw = 0;
-    while (s < s1) {
-        const uint32_t nwin = m.slot_nwin[s];
-        uint32_t ns = s, nw = w + 1;
-        if (nw == nwin) { ns = s + 1; nw = 0; }
-        if (ns < s1) ZKP_MSM_DMA(cur ^ 1u, m.slot_base[ns], nw);   // lands while this window is being added
-        if ((w & 3u) == 0) dw = active ? m.digits[((size_t)s * 8 + (w >> 2)) * m.rows + row] : 0u;
-        const int32_t d = (int32_t)(int8_t)(dw >> (8 * (w & 3u)));
-        if (d != 0) acc = msm_accumulate_digit(acc, d, reinterpret_cast<const uint32_t*>(lds4[cur]));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
-        __syncthreads();                                   // every wave's pieces landed; every wave is done reading `cur`
-        s = ns; w = nw; cur ^= 1u;
-    }
-#undef ZKP_MSM_DMA
-    if (active) st_ge(m.partial, chunk, row, m.rows, acc);
-}
+struct EdMsm {      // edwards25519 affine-Niels tables, extended-coordinate accumulator (Bulletproofs path)
+    static constexpr uint32_t AFF_W = NIELS_W, ACC_W = GE_W;
+    using Acc = ge;
+    static __device__ __forceinline__ Acc identity() { return ge_identity(); }
+    static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) { return msm_accumulate_digit(acc, d, subtab); }
+    static __device__ __forceinline__ void store(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const Acc& a) { st_ge(p, idx, row, rows, a); }
+    static __device__ __forceinline__ Acc load(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) { return ld_ge(p, idx, row, rows); }
+    static __device__ __forceinline__ Acc add(const Acc& a, const Acc& b) { return ge_add(a, b); }
+};
+
+template __global__ void k_msm_dma<EdMsm>(MsmView, uint32_t, uint32_t);
+template __global__ void k_sum_t<EdMsm>(ReduceView, uint32_t*);
 
 // ================================================================================================ host
 namespace {
@@ -331,7 +266,7 @@ int init_locked(int device) {
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
     g.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, g_msm_variant == 1 ? k_msm : k_msm_dma, MSM_TB, 0) == hipSuccess && occ > 0) g.msm_blocks_per_cu = occ;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, g_msm_variant == 1 ? k_msm : k_msm_dma<EdMsm>, MSM_TB, 0) == hipSuccess && occ > 0) g.msm_blocks_per_cu = occ;
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&g.start_ev, hipEventDisableTiming));
     // generator tables (one-time, host)
@@ -416,7 +351,7 @@ int ensure_workspace(SubBatch& sb, uint32_t M, uint32_t C) {
 
 int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32_t* partial, hipStream_t st) {
     MsmView m; m.rows = rows; m.nslots = D.nslots; m.nchunks = D.nchunks; m.table = g.d_table; m.digits = digits;
-    m.slot_base = D.slot_base; m.slot_nwin = D.slot_nwin; m.chunk_begin = D.chunk_begin; m.partial = partial;
+    m.slot_base = D.slot_base; m.slot_scalar = nullptr; m.slot_nwin = D.slot_nwin; m.chunk_begin = D.chunk_begin; m.partial = partial;
     const uint32_t ngroups = (rows + MSM_TB - 1) / MSM_TB, nblocks = D.nchunks * ngroups;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -428,14 +363,14 @@ int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32
         HIP_TRY(hipEventRecord(e0, st));
     }
     if (g_msm_variant == 1) k_msm<<<grid, MSM_TB, 0, st>>>(m, ngroups, nblocks);
-    else k_msm_dma<<<grid, MSM_TB, 0, st>>>(m, ngroups, nblocks);
+    else k_msm_dma<EdMsm><<<grid, MSM_TB, 0, st>>>(m, ngroups, nblocks);
     if (g.profiling) { HIP_TRY(hipEventRecord(e1, st)); g.msm_launches++; g.msm_adds += D.adds_per_row * rows; }
     return 0;
 }
 int launch_reduce(const DevLayout& D, uint32_t rows, const uint32_t* partial, uint32_t* sums, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
     ReduceView R; R.rows = rows; R.ntargets = D.ntargets; R.partial = partial; R.target_chunk_begin = D.target_chunk_begin;
     R.enc = enc; R.out_off = out_off; R.out = out;
-    k_sum<<<dim3((rows + 7) / 8, D.ntargets), TW, 0, st>>>(R, sums);
+    k_sum_t<EdMsm><<<dim3((rows + 7) / 8, D.ntargets), TW, 0, st>>>(R, sums);
     k_encode<<<dim3((rows + TW - 1) / TW, D.ntargets), TW, 0, st>>>(R, sums);
     return 0;
 }
@@ -608,6 +543,8 @@ int fresh_seeds(std::vector<uint8_t>& buf, size_t n) {
 }
 
 }  // namespace
+
+#include "g16_impl.inc"
 
 // ================================================================================================ C ABI
 extern "C" {

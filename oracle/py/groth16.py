@@ -299,6 +299,16 @@ def setup(cs, setup_seed, circuit_tag):
     return pk
 
 
+def serialize_pk(pk):
+    """ark-serialize uncompressed ProvingKey<Bn254>: vk{alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1}, beta_g1,
+    delta_g1, a_query, b_g1_query, b_g2_query, h_query, l_query; Vec = u64 LE length + items."""
+    def vec(items, ser):
+        return len(items).to_bytes(8, "little") + b"".join(ser(x) for x in items)
+    return (bn.ser_g1(pk.alpha_g1) + bn.ser_g2(pk.beta_g2) + bn.ser_g2(pk.gamma_g2) + bn.ser_g2(pk.delta_g2) + vec(pk.gamma_abc_g1, bn.ser_g1)
+            + bn.ser_g1(pk.beta_g1) + bn.ser_g1(pk.delta_g1) + vec(pk.a_query, bn.ser_g1) + vec(pk.b_g1_query, bn.ser_g1)
+            + vec(pk.b_g2_query, bn.ser_g2) + vec(pk.h_query, bn.ser_g1) + vec(pk.l_query, bn.ser_g1))
+
+
 # ---------------------------------------------------------------- prover (create_proof_with_reduction) and verifier
 def prove(pk, cs, r, s):
     assert is_satisfied(cs)

@@ -18,7 +18,7 @@ struct DevLayout { MsmLayout L; };
 
 static void run_msm(const MsmLayout& L, uint32_t rows, const uint32_t* digits, std::vector<uint32_t>& partial) {
     MsmView m; m.rows = rows; m.nslots = L.nslots(); m.nchunks = L.nchunks(); m.table = g_table.data(); m.digits = digits;
-    m.slot_base = L.slot_base.data(); m.slot_nwin = L.slot_nwin.data(); m.chunk_begin = L.chunk_begin.data();
+    m.slot_base = L.slot_base.data(); m.slot_scalar = nullptr; m.slot_nwin = L.slot_nwin.data(); m.chunk_begin = L.chunk_begin.data();
     partial.assign((size_t)L.nchunks() * GE_W * rows, 0); m.partial = partial.data();
     for (uint32_t c = 0; c < L.nchunks(); c++) for (uint32_t row = 0; row < rows; row++) msm_chunk_ref(m, c, row);
 }
