@@ -6,6 +6,8 @@ HIP library behind the C ABI of include/libzkp_hip.h; there is no CPU fallback.
 """
 from .api import (  # noqa: F401
     prove_range, prove_range_batch, prove_threshold, prove_threshold_batch, prove_consistency, prove_consistency_batch,
+    prove_equality, prove_equality_batch, prove_equality_advanced, prove_membership, prove_membership_batch, snark_commit_value,
+    snark_commit_value_batch, set_snark_key_dir, is_snark_setup_initialized,
     create_proof_batch, batch_add_range_proof, batch_add_equality_proof,
     batch_add_threshold_proof, batch_add_membership_proof, batch_add_improvement_proof, batch_add_consistency_proof,
     process_batch, get_batch_status, clear_batch, benchmark_proof_generation, benchmark_proof_generation_numeric,
@@ -15,6 +17,8 @@ from ._native import NativeError  # noqa: F401
 
 __all__ = [
     "prove_range", "prove_range_batch", "prove_threshold", "prove_threshold_batch", "prove_consistency", "prove_consistency_batch",
+    "prove_equality", "prove_equality_batch", "prove_equality_advanced", "prove_membership", "prove_membership_batch", "snark_commit_value",
+    "snark_commit_value_batch", "set_snark_key_dir", "is_snark_setup_initialized",
     "create_proof_batch", "batch_add_range_proof", "batch_add_equality_proof",
     "batch_add_threshold_proof", "batch_add_membership_proof", "batch_add_improvement_proof", "batch_add_consistency_proof",
     "process_batch", "get_batch_status", "clear_batch", "benchmark_proof_generation", "benchmark_proof_generation_numeric",

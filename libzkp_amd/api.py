@@ -169,6 +169,138 @@ def prove_consistency(data):
     return prove_consistency_batch([list(data)])[0]
 
 
+# ---------------------------------------------------------------- Groth16 (equality / membership), snark.rs
+MAX_SET_SIZE = 64
+_key_dir_override = None
+_keys_loaded = {}
+_KEY_PREFIX = {0: "equality_mimc", 1: "membership_mimc"}          # snark.rs:306,327
+_snark_lock = threading.Lock()
+
+
+def set_snark_key_dir(path):
+    """snark.rs:141-170 (ConfigError -> TypeError, error_handling.rs:43-45).  Must precede the first SNARK proof."""
+    global _key_dir_override
+    if not path:
+        raise TypeError("SNARK key directory cannot be empty")
+    with _snark_lock:
+        if _keys_loaded:
+            raise TypeError("SNARK setup is already initialized; set LIBZKP_SNARK_KEY_DIR before first proof")
+        if _key_dir_override is not None and _key_dir_override != path:
+            raise TypeError("SNARK key directory already set to %s; new value %s rejected" % (_key_dir_override, path))
+        _key_dir_override = path
+    return True
+
+
+def is_snark_setup_initialized():
+    return bool(_keys_loaded)
+
+
+def _ensure_key(kind):
+    """Loads `{dir}/{prefix}_pk.bin` (ark-serialize uncompressed ProvingKey<Bn254>, the reference's own key-file format,
+    snark.rs:31-38,97-112) into the GPU backend."""
+    import os
+    with _snark_lock:
+        if kind in _keys_loaded:
+            return
+        d = _key_dir_override or os.environ.get("LIBZKP_SNARK_KEY_DIR")
+        if not d:
+            raise ZkpBackendError("Configuration error: no SNARK key directory (set_snark_key_dir / LIBZKP_SNARK_KEY_DIR); "
+                                  "generating a fresh trusted setup on the GPU backend is not implemented yet")
+        path = os.path.join(d, _KEY_PREFIX[kind] + "_pk.bin")
+        if not os.path.exists(path):
+            raise ZkpBackendError("Configuration error: proving key %s not found (native key generation not implemented yet)" % path)
+        blob = open(path, "rb").read()
+        rc = _native.lib().zkp_hip_groth16_load_key(kind, blob, len(blob))
+        if rc != 0:
+            raise ZkpBackendError("Configuration error: %s" % _native.last_error())
+        _keys_loaded[kind] = path
+
+
+def snark_commit_value_batch(values):
+    v = np.array([_check_u64("value", x) for x in values], dtype=np.uint64)
+    if len(v) == 0:
+        return []
+    out = np.zeros((len(v), 32), dtype=np.uint8)
+    rc = _native.lib().zkp_hip_snark_commit_value_batch(len(v), _P(v), _P(out))
+    if rc != 0:
+        raise ZkpBackendError("Backend error: %s" % _native.last_error())
+    return [out[i].tobytes() for i in range(len(v))]
+
+
+def snark_commit_value(value):
+    """python_api.rs:32 -> commitment.rs:14-16 (MiMC-5 over BN254 Fr, 32 bytes LE)."""
+    return snark_commit_value_batch([value])[0]
+
+
+def validate_membership_params(value, the_set):
+    """validation.rs:50-63, 91-100."""
+    if len(the_set) == 0:
+        raise ValueError("set cannot be empty")
+    if value not in the_set:
+        raise ValueError("value %d is not in the provided set" % value)
+    if len(the_set) > MAX_SET_SIZE:
+        raise ValueError("set size %d exceeds maximum allowed size %d" % (len(the_set), MAX_SET_SIZE))
+
+
+def prove_equality_batch(vals1, vals2, seeds=None):
+    """Batched prove_equality (equality_proof.rs:10-32): one 298-byte envelope per op."""
+    n = len(vals1)
+    a = np.array([_check_u64("val1", x) for x in vals1], dtype=np.uint64)
+    b = np.array([_check_u64("val2", x) for x in vals2], dtype=np.uint64)
+    if len(b) != n:
+        raise ValueError("vals1, vals2 must have equal length")
+    if (a != b).any():
+        raise ValueError("values are not equal")                     # validation.rs:21-27
+    if n == 0:
+        return []
+    _ensure_key(0)
+    keep, sp = _seed_ptr(seeds, n)
+    out = np.zeros((n, 298), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint32)
+    st = np.zeros(n, dtype=np.int32)
+    rc = _native.lib().zkp_hip_prove_equality_batch(n, _P(a), _P(b), sp, _P(out), 298, _P(lens), _P(st))
+    if rc != 0:
+        raise ZkpBackendError("Proof generation failed: SNARK proof generation failed%s" % (": " + _native.last_error() if rc < 0 else ""))
+    return [out[i, : lens[i]].tobytes() for i in range(n)]
+
+
+def prove_membership_batch(values, sets, seeds=None):
+    """Batched prove_membership (set_membership.rs:12-38)."""
+    n = len(values)
+    vs = [_check_u64("value", x) for x in values]
+    ss = [[_check_u64("set element", x) for x in s] for s in sets]
+    for v, s in zip(vs, ss):
+        validate_membership_params(v, s)
+    if n == 0:
+        return []
+    _ensure_key(1)
+    flat = np.array([x for s in ss for x in s], dtype=np.uint64)
+    counts = np.array([len(s) for s in ss], dtype=np.uint32)
+    va = np.array(vs, dtype=np.uint64)
+    stride = 10 + 4 + 8 * int(counts.max()) + 256 + 32
+    keep, sp = _seed_ptr(seeds, n)
+    out = np.zeros((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint32)
+    st = np.zeros(n, dtype=np.int32)
+    rc = _native.lib().zkp_hip_prove_membership_batch(n, _P(va), _P(flat), _P(counts), sp, _P(out), stride, _P(lens), _P(st))
+    if rc != 0:
+        raise ZkpBackendError("Proof generation failed: SNARK membership proof generation failed%s" % (": " + _native.last_error() if rc < 0 else ""))
+    return [out[i, : lens[i]].tobytes() for i in range(n)]
+
+
+def prove_equality(val1, val2):
+    return prove_equality_batch([val1], [val2])[0]
+
+
+def prove_equality_advanced(val1, val2):
+    """advanced/mod.rs:193-196: same semantics as prove_equality."""
+    return prove_equality(val1, val2)
+
+
+def prove_membership(value, set):  # noqa: A002
+    return prove_membership_batch([value], [list(set)])[0]
+
+
 def prove_range(value, min, max):  # noqa: A002  (reference argument names)
     value, mn, mx = _check_u64("value", value), _check_u64("min", min), _check_u64("max", max)
     validate_range_params(value, mn, mx)
@@ -178,8 +310,8 @@ def prove_range(value, min, max):  # noqa: A002  (reference argument names)
 # ---------------------------------------------------------------- batch registry (batch.rs:18-175)
 _registry = {}
 _registry_lock = threading.Lock()
-_OUT_OF_SCOPE = ("%s proofs are produced by the %s backend, which this round's HIP path does not cover yet "
-                 "(SURVEY.md section 8: Bulletproofs range path first)")
+_OUT_OF_SCOPE = ("%s proofs are produced by the %s backend, which the HIP path does not cover yet "
+                 "(SURVEY.md section 8 row a11; byte-level parity with Winterfell is unpinnable here)")
 
 
 def create_proof_batch():
@@ -205,6 +337,7 @@ def batch_add_range_proof(batch_id, value, min, max):  # noqa: A002
 
 
 def batch_add_equality_proof(batch_id, val1, val2):
+    val1, val2 = _check_u64("val1", val1), _check_u64("val2", val2)
     if val1 != val2:
         raise ValueError("values are not equal")
     _with_batch(batch_id, ("equality", val1, val2))
@@ -217,11 +350,13 @@ def batch_add_threshold_proof(batch_id, values, threshold):
 
 
 def batch_add_membership_proof(batch_id, value, set):  # noqa: A002
-    if not set:
+    value = _check_u64("value", value)
+    the_set = [_check_u64("set element", x) for x in set]
+    if not the_set:                                                  # batch.rs:94-97 validates membership only
         raise ValueError("set cannot be empty")
-    if value not in set:
+    if value not in the_set:
         raise ValueError("value %d is not in the provided set" % value)
-    _with_batch(batch_id, ("membership", value, tuple(set)))
+    _with_batch(batch_id, ("membership", value, tuple(the_set)))
 
 
 def batch_add_improvement_proof(batch_id, old, new):
@@ -243,15 +378,16 @@ def process_batch(batch_id, seeds=None):
             raise ValueError("Invalid batch ID: %d" % batch_id)
         ops = _registry.pop(batch_id)
     for op in ops:
-        if op[0] not in ("range", "threshold", "consistency"):
-            backend = {"equality": "Groth16", "membership": "Groth16", "improvement": "STARK"}[op[0]]
-            raise NotImplementedError(_OUT_OF_SCOPE % (op[0], backend))
+        if op[0] == "improvement":
+            raise NotImplementedError(_OUT_OF_SCOPE % (op[0], "STARK"))
+        if op[0] == "membership" and len(op[2]) > MAX_SET_SIZE:      # set_membership.rs:14 (validate_set_size at prove time)
+            raise ValueError("set size %d exceeds maximum allowed size %d" % (len(op[2]), MAX_SET_SIZE))
     # bucket by variant (one batched device call each), then restore insertion order (batch.rs:123-131 is order-preserving)
     seeds = None if seeds is None else bytes(seeds)
     if seeds is not None and len(seeds) != 32 * len(ops):
         raise ValueError("seeds must hold 32 bytes per op")
     out = [None] * len(ops)
-    for kind in ("range", "threshold", "consistency"):
+    for kind in ("range", "threshold", "consistency", "equality", "membership"):
         idx = [i for i, o in enumerate(ops) if o[0] == kind]
         if not idx:
             continue
@@ -261,8 +397,12 @@ def process_batch(batch_id, seeds=None):
             proofs = prove_range_batch([o[1] for o in sel], [o[2] for o in sel], [o[3] for o in sel], seeds=sd)
         elif kind == "threshold":
             proofs = prove_threshold_batch([o[1] for o in sel], [o[2] for o in sel], seeds=sd)
-        else:
+        elif kind == "consistency":
             proofs = prove_consistency_batch([o[1] for o in sel], seeds=sd)
+        elif kind == "equality":
+            proofs = prove_equality_batch([o[1] for o in sel], [o[2] for o in sel], seeds=sd)
+        else:
+            proofs = prove_membership_batch([o[1] for o in sel], [list(o[2]) for o in sel], seeds=sd)
         for i, p in zip(idx, proofs):
             out[i] = p
     return out
@@ -289,10 +429,12 @@ def clear_batch(batch_id):
 def benchmark_proof_generation_numeric(proof_type, iterations):
     runners = {"range": lambda: prove_range(50, 0, 100),                          # mod.rs:94-104 fixed inputs
                "threshold": lambda: prove_threshold([10, 20, 30, 40], 50),
-               "consistency": lambda: prove_consistency([10, 20, 30, 40, 50])}
+               "consistency": lambda: prove_consistency([10, 20, 30, 40, 50]),
+               "equality": lambda: prove_equality(42, 42),
+               "membership": lambda: prove_membership(25, [10, 20, 25, 30, 40])}
     if proof_type not in runners:
-        if proof_type in ("equality", "membership", "improvement"):
-            raise NotImplementedError(_OUT_OF_SCOPE % (proof_type, "Groth16/STARK"))
+        if proof_type == "improvement":
+            raise NotImplementedError(_OUT_OF_SCOPE % (proof_type, "STARK"))
         raise ValueError("unsupported proof type: %s" % proof_type)
     times = []
     for _ in range(iterations):

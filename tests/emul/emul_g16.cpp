@@ -1,0 +1,51 @@
+// TEST INFRASTRUCTURE: host run of the Groth16 witness + QAP steps (the per-proof work before the MSMs) so the no-GPU
+// tier can compare the full assignment z and the quotient coefficients h with the oracle.
+#include "../../libzkp_amd/csrc/g16_circuit.h"
+using namespace zkp;
+
+struct NoSync { void operator()() const {} };
+
+extern "C" {
+// kind 0 equality / 1 membership.  Outputs: z_raw [nv][8] canonical words, h_raw [m-1][8], envelope prefix bytes.
+// h is returned through its signed digits (what the MSM consumes), re-assembled to the canonical value.
+int emul_g16_witness_qap(int kind, uint64_t value, const uint64_t* set_vals, uint32_t set_len, const uint8_t seed[32],
+                         uint32_t* z_raw, uint32_t* h_raw, uint32_t* rs_raw, uint8_t* out, uint64_t stride, uint32_t* shape) {
+    const HostR1CS cs = kind == 0 ? build_equality_r1cs() : build_membership_r1cs();
+    const HostCircuitTables T = build_circuit_tables(cs);
+    ensure_mimc_constants();
+    std::vector<uint32_t> mc; for (auto& c : g_mimc_host) put_fr(mc, c);
+    const uint32_t nsc = g16_nscalars(T.nv, T.m);
+    std::vector<uint32_t> z((size_t)T.nv * 8), sdig((size_t)nsc * 8), rs(16), seedw(8);
+    memcpy(seedw.data(), seed, 32);
+    uint64_t sv[G16_MAX_SET] = {0}; for (uint32_t i = 0; i < set_len && i < G16_MAX_SET; i++) sv[i] = set_vals[i];
+    G16View V{}; V.rows = 1; V.kind = (uint32_t)kind; V.n_inst = T.n_inst; V.n_wit = T.n_wit; V.nv = T.nv; V.m = T.m;
+    V.value = &value; V.set_vals = sv; V.set_len = &set_len; V.seeds = seedw.data(); V.mimc_c = mc.data();
+    V.z = z.data(); V.sdig = sdig.data(); V.rs = rs.data(); V.out = out; V.stride = stride;
+    step_g16_witness(V, 0);
+    for (uint32_t k = 0; k < T.nv; k++) step_g16_zdigits(V, k, 0);
+    G16Circuit C{}; C.n_rows = T.n_rows; C.m = T.m; C.logm = T.logm;
+    C.a_ptr = T.ptr[0].data(); C.a_col = T.col[0].data(); C.a_coef = T.coef[0].data();
+    C.b_ptr = T.ptr[1].data(); C.b_col = T.col[1].data(); C.b_coef = T.coef[1].data();
+    C.c_ptr = T.ptr[2].data(); C.c_col = T.col[2].data(); C.c_coef = T.coef[2].data();
+    C.tw = T.tw.data(); C.tw_inv = T.tw_inv.data(); C.coset = T.coset.data(); C.coset_inv = T.coset_inv.data(); C.zinv = T.zinv.data();
+    std::vector<uint32_t> lds((size_t)3 * 8 * T.m);
+    G16Lds L; L.base = lds.data(); L.m = T.m;
+    g16_qap_proof(V, C, L, 0, 0, 1, NoSync());
+    for (uint32_t k = 0; k < T.nv; k++) { fr x = ld_fr(z.data(), k, 0, 1); fp_to_raw(z_raw + 8 * k, x); }
+    // digits -> canonical value (sum d_j 256^j), as 8 words via a small signed accumulate
+    auto undigit = [&](uint32_t idx, uint32_t* outw) {
+        int64_t carry = 0; uint8_t bytes[33] = {0};
+        for (int j = 0; j < 32; j++) {
+            const int32_t d = (int32_t)(int8_t)(sdig[(size_t)idx * 8 + (j >> 2)] >> (8 * (j & 3)));
+            int64_t v = d + carry; carry = 0;
+            if (v < 0) { v += 256; carry = -1; }
+            bytes[j] = (uint8_t)v;
+        }
+        memcpy(outw, bytes, 32);
+    };
+    for (uint32_t i = 0; i + 1 < T.m; i++) undigit(g16_sc_h(V) + i, h_raw + 8 * i);
+    memcpy(rs_raw, rs.data(), 64);
+    shape[0] = T.n_inst; shape[1] = T.n_wit; shape[2] = T.n_rows; shape[3] = T.m;
+    return 0;
+}
+}

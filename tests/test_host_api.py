@@ -56,6 +56,19 @@ def test_threshold_and_consistency_validation_messages():
         z.prove_consistency([1, 3, 2])
 
 
+def test_snark_validation_messages():
+    with pytest.raises(ValueError, match="^values are not equal$"):
+        z.prove_equality(1, 2)
+    with pytest.raises(ValueError, match="^set cannot be empty$"):
+        z.prove_membership(1, [])
+    with pytest.raises(ValueError, match="^value 5 is not in the provided set$"):
+        z.prove_membership(5, [1, 2, 3])
+    with pytest.raises(ValueError, match="^set size 65 exceeds maximum allowed size 64$"):
+        z.prove_membership(3, list(range(65)))
+    with pytest.raises(TypeError, match="SNARK key directory cannot be empty"):
+        z.set_snark_key_dir("")
+
+
 def test_process_batch_consumes_the_batch_even_on_failure():
     b = z.create_proof_batch()
     z.batch_add_improvement_proof(b, 1, 2)
