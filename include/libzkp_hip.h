@@ -81,6 +81,14 @@ int zkp_hip_prove_consistency_batch(uint64_t n, const uint64_t* data, const uint
  * `{prefix}_pk.bin` key files (snark.rs:31-38,97-112).  Builds the fixed-base tables of every key point on the GPU. */
 int zkp_hip_groth16_load_key(int kind, const uint8_t* pk, uint64_t len);
 
+/* Circuit-specific trusted setup (replaces Groth16::circuit_specific_setup at snark.rs:318,337): toxic waste from
+ * `setup_seed` (32 bytes; NULL = OS randomness, the reference's behaviour), every key point computed on the GPU.
+ * The key is loaded into the backend and also returned in ark-serialize uncompressed form so the caller can persist
+ * `{prefix}_pk.bin` / `{prefix}_vk.bin` exactly like load_or_generate_setup (snark.rs:122-139).  Call with NULL buffers
+ * first to learn the sizes (the key is generated and loaded either way). */
+int zkp_hip_groth16_generate_key(int kind, const uint8_t* setup_seed, uint8_t* pk_out, uint64_t pk_cap, uint64_t* pk_len,
+                                 uint8_t* vk_out, uint64_t vk_cap, uint64_t* vk_len);
+
 /* utils::commitment::commit_value_snark (commitment.rs:14-16; MiMC-5/110 over BN254 Fr, snark.rs:201-221): 32 bytes per value. */
 int zkp_hip_snark_commit_value_batch(uint64_t n, const uint64_t* values, uint8_t* out);
 

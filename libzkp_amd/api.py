@@ -196,23 +196,34 @@ def is_snark_setup_initialized():
 
 
 def _ensure_key(kind):
-    """Loads `{dir}/{prefix}_pk.bin` (ark-serialize uncompressed ProvingKey<Bn254>, the reference's own key-file format,
-    snark.rs:31-38,97-112) into the GPU backend."""
+    """load_or_generate_setup (snark.rs:122-139): loads `{dir}/{prefix}_pk.bin` (ark-serialize uncompressed
+    ProvingKey<Bn254>, the reference's own key-file format) or runs a fresh setup on the GPU and persists it."""
     import os
     with _snark_lock:
         if kind in _keys_loaded:
             return
         d = _key_dir_override or os.environ.get("LIBZKP_SNARK_KEY_DIR")
-        if not d:
-            raise ZkpBackendError("Configuration error: no SNARK key directory (set_snark_key_dir / LIBZKP_SNARK_KEY_DIR); "
-                                  "generating a fresh trusted setup on the GPU backend is not implemented yet")
-        path = os.path.join(d, _KEY_PREFIX[kind] + "_pk.bin")
-        if not os.path.exists(path):
-            raise ZkpBackendError("Configuration error: proving key %s not found (native key generation not implemented yet)" % path)
-        blob = open(path, "rb").read()
-        rc = _native.lib().zkp_hip_groth16_load_key(kind, blob, len(blob))
-        if rc != 0:
-            raise ZkpBackendError("Configuration error: %s" % _native.last_error())
+        L = _native.lib()
+        path = os.path.join(d, _KEY_PREFIX[kind] + "_pk.bin") if d else None
+        if path and os.path.exists(path):
+            blob = open(path, "rb").read()
+            if L.zkp_hip_groth16_load_key(kind, blob, len(blob)) != 0:
+                raise ZkpBackendError("Configuration error: %s" % _native.last_error())
+        else:
+            # load_or_generate_setup (snark.rs:122-139): fresh trusted setup (OS randomness), persisted if a key dir is set
+            pk_len, vk_len = ctypes.c_uint64(), ctypes.c_uint64()
+            cap_pk, cap_vk = 1 << 20, 1 << 16
+            pk, vk = ctypes.create_string_buffer(cap_pk), ctypes.create_string_buffer(cap_vk)
+            if L.zkp_hip_groth16_generate_key(kind, None, pk, cap_pk, ctypes.byref(pk_len), vk, cap_vk, ctypes.byref(vk_len)) != 0:
+                raise ZkpBackendError("Proof generation failed: setup failed: %s" % _native.last_error())
+            if d:
+                try:
+                    os.makedirs(d, exist_ok=True)
+                    open(path, "wb").write(pk.raw[: pk_len.value])
+                    open(os.path.join(d, _KEY_PREFIX[kind] + "_vk.bin"), "wb").write(vk.raw[: vk_len.value])
+                except OSError:
+                    pass                                              # the reference ignores persist errors too (snark.rs:131-133)
+            path = path or "<generated in memory>"
         _keys_loaded[kind] = path
 
 

@@ -87,6 +87,14 @@ __global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, u
 
 
 
+// thread = point: Jacobian sum -> ark-serialize uncompressed affine bytes (key generation output)
+__global__ void __launch_bounds__(TW) k_g16_serialize(bool g2, const uint32_t* jac, uint32_t rows, uint8_t* out) {
+    const uint32_t row = blockIdx.x * TW + threadIdx.x;
+    if (row >= rows) return;
+    if (!g2) { uint32_t w[16]; g1_serialize(w, ld_g1_jac(jac, 0, row, rows)); g16_put_bytes(out + 64ull * row, w, 16); }
+    else { uint32_t w[32]; g2_serialize(w, ld_g2_jac(jac, 0, row, rows)); g16_put_bytes(out + 128ull * row, w, 32); }
+}
+
 template __global__ void k_msm_dma<G1Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_msm_dma<G2Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_sum_t<G1Msm>(ReduceView, uint32_t*);
@@ -120,3 +128,4 @@ void g16_launch_sum(bool g2, const ReduceView& R, uint32_t* sums, hipStream_t st
     if (!g2) k_sum_t<G1Msm><<<dim3((R.rows + 7) / 8, R.ntargets), TW, 0, st>>>(R, sums);
     else k_sum_t<G2Msm><<<dim3((R.rows + 7) / 8, R.ntargets), TW, 0, st>>>(R, sums);
 }
+void g16_launch_serialize(bool g2, const uint32_t* jac, uint32_t rows, uint8_t* out, hipStream_t st) { k_g16_serialize<<<(rows + TW - 1) / TW, TW, 0, st>>>(g2, jac, rows, out); }

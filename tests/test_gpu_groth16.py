@@ -122,6 +122,47 @@ def test_membership_bit_exact_and_verified(hip):
     assert g.verify_membership(out[3, : lens[3]].tobytes(), list(range(64)), SS)
 
 
+def test_native_key_generation_matches_oracle_setup(hip):
+    """Trusted setup on the GPU from the same setup seed == oracle setup == the committed key files, byte for byte;
+    a key from OS randomness differs and still proves."""
+    from libzkp_amd import _native
+    for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")):
+        pk, vk = ctypes.create_string_buffer(1 << 20), ctypes.create_string_buffer(1 << 16)
+        pl, vl = ctypes.c_uint64(), ctypes.c_uint64()
+        assert hip.zkp_hip_groth16_generate_key(kind, SS, pk, 1 << 20, ctypes.byref(pl), vk, 1 << 16, ctypes.byref(vl)) == 0, _native.last_error()
+        ref = open(os.path.join(GOLD, name), "rb").read()
+        assert pk.raw[: pl.value] == ref
+        assert vk.raw[: vl.value] == ref[: vl.value] and vl.value == 64 + 3 * 128 + 8 + 64 * (2 if kind == 0 else 130)
+    pl = ctypes.c_uint64()
+    pk = ctypes.create_string_buffer(1 << 20)
+    assert hip.zkp_hip_groth16_generate_key(0, None, pk, 1 << 20, ctypes.byref(pl), None, 0, None) == 0
+    assert pk.raw[: pl.value] != open(os.path.join(GOLD, "equality_mimc_pk.bin"), "rb").read()
+    a = np.array([77], dtype=np.uint64)
+    out = np.zeros((1, 298), dtype=np.uint8)
+    lens = np.zeros(1, dtype=np.uint32)
+    st = np.zeros(1, dtype=np.int32)
+    assert hip.zkp_hip_prove_equality_batch(1, P(a), P(a), None, P(out), 298, P(lens), P(st)) == 0
+    assert not g.verify_equality_with_commitment(out[0].tobytes(), g.commit_value_snark(77), SS)      # proof under the NEW key
+    blob = open(os.path.join(GOLD, "equality_mimc_pk.bin"), "rb").read()                                # restore the test key
+    assert hip.zkp_hip_groth16_load_key(0, blob, len(blob)) == 0
+    assert hip.zkp_hip_groth16_load_key(0, blob[:-1], len(blob) - 1) == -3                              # truncated key rejected
+
+
+def test_python_api_generates_and_persists_keys(hip, tmp_path):
+    import libzkp_amd as z
+    from libzkp_amd import api
+    api._keys_loaded.clear()
+    api._key_dir_override = None
+    z.set_snark_key_dir(str(tmp_path))
+    p = z.prove_equality(9, 9)
+    assert len(p) == 298 and sorted(os.listdir(tmp_path)) == ["equality_mimc_pk.bin", "equality_mimc_vk.bin"]
+    pk = open(tmp_path / "equality_mimc_pk.bin", "rb").read()
+    assert len(pk) == os.path.getsize(os.path.join(GOLD, "equality_mimc_pk.bin"))
+    api._keys_loaded.clear()                                                   # a second "process" loads the persisted key
+    q = z.prove_equality(9, 9)
+    assert q[266:] == p[266:] and q != p
+
+
 def test_python_api_snark(hip, monkeypatch):
     import libzkp_amd as z
     from libzkp_amd import api
