@@ -88,42 +88,67 @@ inline void host_build_table_for_base(uint32_t* dst, const ge& base) {
 
 // ------------------------------------------------------------------------------------------------
 struct MsmLayout {
-    std::vector<uint16_t> slot_base, chunk_begin, target_chunk_begin;
+    std::vector<uint16_t> slot_base, chunk_begin, chunk_win0, chunk_nwin, target_chunk_begin;
     std::vector<uint8_t> slot_nwin;
     uint32_t nslots() const { return (uint32_t)slot_base.size(); }
-    uint32_t nchunks() const { return (uint32_t)chunk_begin.size() - 1; }
+    uint32_t nchunks() const { return (uint32_t)chunk_begin.size(); }
     uint32_t ntargets() const { return (uint32_t)target_chunk_begin.size() - 1; }
 };
 using SlotList = std::vector<std::pair<uint16_t, uint8_t>>;   // (base, nwin)
 
-// chunks never straddle targets; each chunk holds at most `win_budget` windows of work
+// chunks never straddle targets; slot-aligned chunks of at most `win_budget` windows of work
 inline MsmLayout make_layout(const std::vector<SlotList>& targets, uint32_t win_budget) {
     MsmLayout L;
-    L.chunk_begin.push_back(0); L.target_chunk_begin.push_back(0);
+    L.target_chunk_begin.push_back(0);
     for (const auto& t : targets) {
-        uint32_t used = 0;
+        uint32_t used = 0; bool open = false;
         for (const auto& s : t) {
-            if (used > 0 && used + s.second > win_budget) { L.chunk_begin.push_back((uint16_t)L.slot_base.size()); used = 0; }
+            if (open && used + s.second > win_budget) { L.chunk_nwin.push_back((uint16_t)used); used = 0; open = false; }
+            if (!open) { L.chunk_begin.push_back((uint16_t)L.slot_base.size()); L.chunk_win0.push_back(0); open = true; }
             L.slot_base.push_back(s.first); L.slot_nwin.push_back(s.second); used += s.second;
         }
-        L.chunk_begin.push_back((uint16_t)L.slot_base.size());
-        L.target_chunk_begin.push_back((uint16_t)(L.chunk_begin.size() - 1));
+        if (open) L.chunk_nwin.push_back((uint16_t)used);
+        L.target_chunk_begin.push_back((uint16_t)L.chunk_begin.size());
     }
     return L;
 }
-inline MsmLayout layout_phase1(uint32_t budget) {
+// window-granular chunks: about `total_chunks` chunks of (nearly) equal work, distributed over the targets in proportion
+// to their window counts, so that nchunks * (row groups) can be matched to the number of resident workgroups
+inline MsmLayout make_layout_even(const std::vector<SlotList>& targets, uint32_t total_chunks) {
+    MsmLayout L;
+    uint64_t W = 0; for (const auto& t : targets) for (const auto& s : t) W += s.second;
+    L.target_chunk_begin.push_back(0);
+    for (const auto& t : targets) {
+        uint32_t wt = 0; for (const auto& s : t) wt += s.second;
+        uint32_t k = (uint32_t)((uint64_t)total_chunks * wt / (W ? W : 1));
+        if (k < 1) k = 1;
+        if (k > wt && wt) k = wt;
+        const uint32_t slot0 = (uint32_t)L.slot_base.size();
+        for (const auto& s : t) { L.slot_base.push_back(s.first); L.slot_nwin.push_back(s.second); }
+        // walk the flattened (slot, window) sequence and cut it into k ranges
+        uint32_t slot = slot0, win = 0, done = 0;
+        for (uint32_t c = 0; c < k; c++) {
+            const uint32_t upto = (uint32_t)((uint64_t)wt * (c + 1) / k), n = upto - done;
+            if (n == 0) continue;
+            L.chunk_begin.push_back((uint16_t)slot); L.chunk_win0.push_back((uint16_t)win); L.chunk_nwin.push_back((uint16_t)n);
+            uint32_t left = n;
+            while (left) { const uint32_t room = L.slot_nwin[slot] - win, step = left < room ? left : room; win += step; left -= step; if (win == L.slot_nwin[slot]) { slot++; win = 0; } }
+            done = upto;
+        }
+        L.target_chunk_begin.push_back((uint16_t)L.chunk_begin.size());
+    }
+    return L;
+}
+inline std::vector<SlotList> targets_phase1() {
     SlotList v = {{BASE_B, 9}, {BASE_BB, 32}}, a = {{BASE_BB, 32}}, s = {{BASE_BB, 32}};
     for (uint32_t i = 0; i < BP_N; i++) a.push_back({(uint16_t)(BASE_G + i), 1});
     for (uint32_t i = 0; i < BP_N; i++) a.push_back({(uint16_t)(BASE_H + i), 1});
     for (uint32_t i = 0; i < BP_N; i++) s.push_back({(uint16_t)(BASE_G + i), 32});
     for (uint32_t i = 0; i < BP_N; i++) s.push_back({(uint16_t)(BASE_H + i), 32});
-    return make_layout({v, a, s}, budget);
+    return {v, a, s};
 }
-inline MsmLayout layout_phase2(uint32_t budget) {
-    SlotList t = {{BASE_B, 32}, {BASE_BB, 32}};
-    return make_layout({t, t}, budget);
-}
-inline MsmLayout layout_round(uint32_t r, uint32_t budget) {
+inline std::vector<SlotList> targets_phase2() { SlotList t = {{BASE_B, 32}, {BASE_BB, 32}}; return {t, t}; }
+inline std::vector<SlotList> targets_round(uint32_t r) {
     const uint32_t p = 5 - r, k = 1u << p;
     auto idx = [&](uint32_t rank, uint32_t bit) { return ((rank >> p) << (p + 1)) | (bit << p) | (rank & (k - 1)); };
     SlotList l = {{BASE_B, 32}}, rr = {{BASE_B, 32}};
@@ -131,8 +156,12 @@ inline MsmLayout layout_round(uint32_t r, uint32_t budget) {
     for (uint32_t q = 0; q < 32; q++) l.push_back({(uint16_t)(BASE_H + idx(q, 0)), 32});
     for (uint32_t q = 0; q < 32; q++) rr.push_back({(uint16_t)(BASE_G + idx(q, 0)), 32});
     for (uint32_t q = 0; q < 32; q++) rr.push_back({(uint16_t)(BASE_H + idx(q, 1)), 32});
-    return make_layout({l, rr}, budget);
+    return {l, rr};
 }
-inline MsmLayout layout_ctask(uint32_t budget) { return make_layout({SlotList{{BASE_B, 9}, {BASE_BB, 32}}}, budget); }
+inline std::vector<SlotList> targets_ctask() { return {SlotList{{BASE_B, 9}, {BASE_BB, 32}}}; }
+inline MsmLayout layout_phase1(uint32_t budget) { return make_layout(targets_phase1(), budget); }
+inline MsmLayout layout_phase2(uint32_t budget) { return make_layout(targets_phase2(), budget); }
+inline MsmLayout layout_round(uint32_t r, uint32_t budget) { return make_layout(targets_round(r), budget); }
+inline MsmLayout layout_ctask(uint32_t budget) { return make_layout(targets_ctask(), budget); }
 
 }  // namespace zkp

@@ -158,19 +158,20 @@ struct MsmView {
     const uint16_t* slot_base;   // [nslots] which table (generator / key point) a slot uses
     const uint16_t* slot_scalar; // [nslots] which digit row a slot reads (nullptr: row = slot)
     const uint8_t* slot_nwin;    // [nslots] number of low windows that may be non-zero
-    const uint16_t* chunk_begin; // [nchunks + 1] slot ranges
+    const uint16_t* chunk_begin; // [nchunks] first slot of a chunk
+    const uint16_t* chunk_win0;  // [nchunks] first window inside that slot (chunks are window-granular)
+    const uint16_t* chunk_nwin;  // [nchunks] number of (slot, window) steps in the chunk
     uint32_t* partial;           // [nchunks][40][rows]
 };
 ZKP_HD inline void msm_chunk_ref(const MsmView& m, uint32_t chunk, uint32_t row) {
     ge acc = ge_identity();
-    for (uint32_t s = m.chunk_begin[chunk]; s < m.chunk_begin[chunk + 1]; s++) {
-        const uint32_t base = m.slot_base[s], nwin = m.slot_nwin[s];
-        for (uint32_t w = 0; w < nwin; w++) {
-            const uint32_t srow = m.slot_scalar ? m.slot_scalar[s] : s;
-            const uint32_t word = m.digits[((size_t)srow * 8 + (w >> 2)) * m.rows + row];
-            const int32_t d = (int32_t)(int8_t)(word >> (8 * (w & 3)));
-            if (d != 0) acc = msm_accumulate_digit(acc, d, m.table + ((size_t)base * NWIN + w) * SUBTAB_W);
-        }
+    uint32_t s = m.chunk_begin[chunk], w = m.chunk_win0[chunk];
+    for (uint32_t left = m.chunk_nwin[chunk]; left > 0; left--) {
+        const uint32_t srow = m.slot_scalar ? m.slot_scalar[s] : s;
+        const uint32_t word = m.digits[((size_t)srow * 8 + (w >> 2)) * m.rows + row];
+        const int32_t d = (int32_t)(int8_t)(word >> (8 * (w & 3)));
+        if (d != 0) acc = msm_accumulate_digit(acc, d, m.table + ((size_t)m.slot_base[s] * NWIN + w) * SUBTAB_W);
+        if (++w == m.slot_nwin[s]) { s++; w = 0; }
     }
     st_ge(m.partial, chunk, row, m.rows, acc);
 }

@@ -24,8 +24,7 @@ __global__ void __launch_bounds__(MSM_TB) k_msm_dma(MsmView m, uint32_t ngroups,
     const uint32_t chunk = linear / ngroups, group = linear % ngroups;
     const uint32_t row = group * MSM_TB + tid;
     const bool active = row < m.rows;
-    const uint32_t s1 = m.chunk_begin[chunk + 1];
-    uint32_t s = m.chunk_begin[chunk], w = 0, cur = 0;
+    uint32_t s = m.chunk_begin[chunk], w = m.chunk_win0[chunk], left = m.chunk_nwin[chunk], cur = 0;
     typename T::Acc acc = T::identity();
 #define ZKP_MSM_DMA(buf_, base_, win_)                                                                              \
     do {                                                                                                            \
@@ -36,16 +35,18 @@ __global__ void __launch_bounds__(MSM_TB) k_msm_dma(MsmView m, uint32_t ngroups,
                 __builtin_amdgcn_global_load_lds(src_ + first_ + lane, &lds4[buf_][first_], 16, 0, 0);              \
         }                                                                                                           \
     } while (0)
-    if (s < s1) ZKP_MSM_DMA(0, m.slot_base[s], 0);
+    if (left) ZKP_MSM_DMA(0, m.slot_base[s], w);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     uint32_t dw = 0;
-    while (s < s1) {
+    bool fresh = true;                                            // first window of the chunk may start mid-word
+    while (left) {
         const uint32_t nwin = m.slot_nwin[s];
         uint32_t ns = s, nw = w + 1;
         if (nw == nwin) { ns = s + 1; nw = 0; }
-        if (ns < s1) ZKP_MSM_DMA(cur ^ 1u, m.slot_base[ns], nw);   // lands while this window is being added
-        if ((w & 3u) == 0) {
+        if (left > 1) ZKP_MSM_DMA(cur ^ 1u, m.slot_base[ns], nw);   // lands while this window is being added
+        if ((w & 3u) == 0 || fresh) {
+            fresh = false;
             const uint32_t srow = m.slot_scalar ? m.slot_scalar[s] : s;
             dw = active ? m.digits[((size_t)srow * 8 + (w >> 2)) * m.rows + row] : 0u;
         }
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(MSM_TB) k_msm_dma(MsmView m, uint32_t ngroups,
         if (d != 0) acc = T::accumulate(acc, d, reinterpret_cast<const uint32_t*>(lds4[cur]));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
         __syncthreads();                                   // every wave's pieces landed; every wave is done reading `cur`
-        s = ns; w = nw; cur ^= 1u;
+        s = ns; w = nw; cur ^= 1u; left--;
     }
 #undef ZKP_MSM_DMA
     if (active) T::store(m.partial, chunk, row, m.rows, acc);

@@ -18,7 +18,7 @@ struct DevLayout { MsmLayout L; };
 
 static void run_msm(const MsmLayout& L, uint32_t rows, const uint32_t* digits, std::vector<uint32_t>& partial) {
     MsmView m; m.rows = rows; m.nslots = L.nslots(); m.nchunks = L.nchunks(); m.table = g_table.data(); m.digits = digits;
-    m.slot_base = L.slot_base.data(); m.slot_scalar = nullptr; m.slot_nwin = L.slot_nwin.data(); m.chunk_begin = L.chunk_begin.data();
+    m.slot_base = L.slot_base.data(); m.slot_scalar = nullptr; m.slot_nwin = L.slot_nwin.data(); m.chunk_begin = L.chunk_begin.data(); m.chunk_win0 = L.chunk_win0.data(); m.chunk_nwin = L.chunk_nwin.data();
     partial.assign((size_t)L.nchunks() * GE_W * rows, 0); m.partial = partial.data();
     for (uint32_t c = 0; c < L.nchunks(); c++) for (uint32_t row = 0; row < rows; row++) msm_chunk_ref(m, c, row);
 }
@@ -58,23 +58,24 @@ int emul_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* mn
     std::vector<uint32_t> ctd((size_t)2 * 8 * C), ctenc((size_t)8 * C);
     CtView T{C, ctv.data(), ctsix.data(), ctbl.data(), seedw.data(), ctd.data()};
     for (uint32_t c = 0; c < C; c++) step_ctask(T, c);
-    MsmLayout Lc = layout_ctask(win_budget);
+    const bool even = win_budget >= 10000; const uint32_t nch = win_budget - 10000;
+    MsmLayout Lc = even ? make_layout_even(targets_ctask(), nch) : layout_ctask(win_budget);
     run_msm(Lc, C, ctd.data(), partial); run_reduce(Lc, C, partial, ctenc.data(), ctoff.data(), out);
 
     for (uint32_t slot = 0; slot <= TAPE_SLOTS; slot++) for (uint32_t j = 0; j < M; j++) step_tape(V, slot, j);
-    MsmLayout L1 = layout_phase1(win_budget);
+    MsmLayout L1 = even ? make_layout_even(targets_phase1(), nch) : layout_phase1(win_budget);
     run_msm(L1, M, V.d1, partial); run_reduce(L1, M, partial, V.enc, nullptr, nullptr);
     for (uint32_t j = 0; j < M; j++) step_transcript1(V, j, s);
     for (uint32_t i = 0; i < BP_N; i++) for (uint32_t j = 0; j < M; j++) step_poly(V, i, j);
     for (uint32_t j = 0; j < M; j++) step_poly_sum(V, j);
-    MsmLayout L2 = layout_phase2(win_budget);
+    MsmLayout L2 = even ? make_layout_even(targets_phase2(), nch) : layout_phase2(win_budget);
     run_msm(L2, M, V.d2, partial); run_reduce(L2, M, partial, V.enc, nullptr, nullptr);
     for (uint32_t j = 0; j < M; j++) step_transcript2(V, j, s);
     for (uint32_t i = 0; i < BP_N; i++) for (uint32_t j = 0; j < M; j++) step_lr_init(V, i, j);
     for (uint32_t r = 0; r < 6; r++) {
         for (uint32_t i = 0; i < BP_N; i++) for (uint32_t j = 0; j < M; j++) step_round_prep(V, r, i, j);
         for (uint32_t j = 0; j < M; j++) step_round_sum(V, r, j);
-        MsmLayout Lr = layout_round(r, win_budget);
+        MsmLayout Lr = even ? make_layout_even(targets_round(r), nch) : layout_round(r, win_budget);
         run_msm(Lr, M, V.dr, partial); run_reduce(Lr, M, partial, V.enc, nullptr, nullptr);
         for (uint32_t j = 0; j < M; j++) step_transcript_round(V, r, j, s);
     }

@@ -113,7 +113,7 @@ def test_prover_steps_equal_oracle(emul, oracle_c, golden_bp):
     v[1], v[2] = 0, 2**32
     mn[3], mx[3], v[3] = 5, 2**64 - 1, 2**63 + 12345
     mn[4], mx[4], v[4] = 9, 9, 9
-    for budget in (128, 32, 1000):
+    for budget in (128, 32, 1000, 10000 + 7, 10000 + 128):      # slot-aligned budgets and window-granular even layouts
         out, lens, st = outputs(n)
         rc = lib.emul_prove_range_batch(U64(n), P(v), P(mn), P(mx), P(seeds), P(out), U64(1478), P(lens), P(st), budget)
         rc2, o2, l2, s2 = oracle_prove(oracle_c, v, mn, mx, seeds, threads=4)
