@@ -3,7 +3,7 @@
 #include "msm_kernel.h"
 
 struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b1/h/l queries)
-    static constexpr uint32_t AFF_W = 16, ACC_W = 24;
+    static constexpr uint32_t AFF_W = 16, ACC_W = 24, MIN_WAVES = 3;
     using Acc = g1_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq>(); }
     static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
@@ -17,7 +17,7 @@ struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b
     static __device__ __forceinline__ Acc add(const Acc& a, const Acc& b) { return jac_add(a, b); }
 };
 struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
-    static constexpr uint32_t AFF_W = 32, ACC_W = 48;
+    static constexpr uint32_t AFF_W = 32, ACC_W = 48, MIN_WAVES = 2;
     using Acc = g2_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq2>(); }
     static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
@@ -48,9 +48,13 @@ __global__ void __launch_bounds__(TB) k_g16_qap(G16View V, G16Circuit C) {
     G16Lds L; L.base = g16_lds; L.m = C.m;
     g16_qap_proof(V, C, L, blockIdx.x, threadIdx.x, TB, DevSync());
 }
-__global__ void __launch_bounds__(TW) k_g16_final(G16View V, const uint32_t* sum_g1, const uint32_t* sum_g2) {
+__global__ void __launch_bounds__(TW) k_g16_cparts(G16View V, const uint32_t* sum_g1, uint32_t* tmp_g1) {
     const uint32_t row = blockIdx.x * TW + threadIdx.x;
-    if (row < V.rows) step_g16_final(V, sum_g1, sum_g2, row);
+    if (row < V.rows) step_g16_cparts(V, sum_g1, tmp_g1, blockIdx.y, row);
+}
+__global__ void __launch_bounds__(TW) k_g16_final(G16View V, const uint32_t* sum_g1, const uint32_t* sum_g2, const uint32_t* tmp_g1) {
+    const uint32_t row = blockIdx.x * TW + threadIdx.x;
+    if (row < V.rows) step_g16_final(V, sum_g1, sum_g2, tmp_g1, blockIdx.y, row);
 }
 __global__ void __launch_bounds__(TW) k_mimc_commit(const uint64_t* values, uint32_t n, const uint32_t* mimc_c, uint8_t* out) {
     const uint32_t i = blockIdx.x * TW + threadIdx.x;
@@ -112,7 +116,10 @@ hipError_t g16_launch_qap(const G16View& V, const G16Circuit& C, hipStream_t st)
     k_g16_qap<<<V.rows, TB, lds, st>>>(V, C);
     return hipSuccess;
 }
-void g16_launch_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* sum_g2, hipStream_t st) { k_g16_final<<<(V.rows + TW - 1) / TW, TW, 0, st>>>(V, sum_g1, sum_g2); }
+void g16_launch_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* sum_g2, uint32_t* tmp_g1, hipStream_t st) {
+    k_g16_cparts<<<dim3((V.rows + TW - 1) / TW, 2), TW, 0, st>>>(V, sum_g1, tmp_g1);
+    k_g16_final<<<dim3((V.rows + TW - 1) / TW, 3), TW, 0, st>>>(V, sum_g1, sum_g2, tmp_g1);
+}
 void g16_launch_mimc(const uint64_t* values, uint32_t n, const uint32_t* mimc_c, uint8_t* out, hipStream_t st) { k_mimc_commit<<<(n + TW - 1) / TW, TW, 0, st>>>(values, n, mimc_c, out); }
 void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uint32_t* table, hipStream_t st) {
     const uint32_t threads = nslots * NWIN;

@@ -228,11 +228,6 @@ ZKP_HD inline void g16_qap_proof(const G16View& V, const G16Circuit& C, const G1
 }
 
 // ---- final assembly.  thread = proof.  sums: [4 targets][words][rows] Jacobian sums A (G1), B1 (G1), Cp (G1), B2 (G2)
-struct G16Final {
-    const uint32_t* sum_g1;      // [3][24][rows]
-    const uint32_t* sum_g2;      // [1][48][rows]
-    const uint32_t* delta_unused;
-};
 ZKP_HD inline g1_jac ld_g1_jac(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) {
     g1_jac r; const uint32_t* q = p + (size_t)idx * 24 * rows + row;
     ZKP_UNROLL for (int k = 0; k < 8; k++) { r.X.v[k] = q[(size_t)k * rows]; r.Y.v[k] = q[(size_t)(8 + k) * rows]; r.Z.v[k] = q[(size_t)(16 + k) * rows]; }
@@ -259,20 +254,28 @@ ZKP_HD inline void st_g2_jac(uint32_t* p, uint32_t idx, uint32_t row, uint32_t r
         q[(size_t)(32 + k) * rows] = g.Z.c0.v[k]; q[(size_t)(40 + k) * rows] = g.Z.c1.v[k];
     }
 }
-// C = Cp + s*A + r*B1 (Cp already contains l_aux, h and -rs*delta); proof = A || B2 || C  (snark.rs:369-373)
-ZKP_HD inline void step_g16_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* sum_g2, uint32_t row) {
+// C = Cp + s*A + r*B1 (Cp already contains l_aux, h and -rs*delta); proof = A || B2 || C  (snark.rs:369-373).
+// Split over lanes: thread (which, row) of step_g16_cparts computes s*A (which = 0) or r*B1 (which = 1); thread
+// (which, row) of step_g16_final serialises A (0), B2 (1) or assembles and serialises C (2).
+ZKP_HD inline void step_g16_cparts(const G16View& V, const uint32_t* sum_g1, uint32_t* tmp_g1, uint32_t which, uint32_t row) {
     const uint32_t rows = V.rows;
-    const g1_jac A = ld_g1_jac(sum_g1, 0, row, rows), B1 = ld_g1_jac(sum_g1, 1, row, rows), Cp = ld_g1_jac(sum_g1, 2, row, rows);
-    const g2_jac B2 = ld_g2_jac(sum_g2, 0, row, rows);
-    const fr rr = ld_fr(V.rs, 0, row, rows), sr = ld_fr(V.rs, 1, row, rows);
-    const g1_jac Cc = jac_add(jac_add(Cp, jac_mul_raw(A, sr.v)), jac_mul_raw(B1, rr.v));
+    const g1_jac P = ld_g1_jac(sum_g1, which, row, rows);                  // A or B1
+    const fr k = ld_fr(V.rs, which == 0 ? 1 : 0, row, rows);               // s for A, r for B1 (raw canonical words)
+    st_g1_jac(tmp_g1, which, row, rows, jac_mul_raw(P, k.v));
+}
+ZKP_HD inline void step_g16_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* sum_g2, const uint32_t* tmp_g1, uint32_t which, uint32_t row) {
+    const uint32_t rows = V.rows;
     uint8_t* o = V.out + (uint64_t)row * V.stride;
     uint32_t plen = 0; for (int k = 0; k < 4; k++) plen |= (uint32_t)o[2 + k] << (8 * k);
     uint8_t* pr = o + 10 + plen - 256;
-    uint32_t w1[16], w2[32];
-    g1_serialize(w1, A); g16_put_bytes(pr, w1, 16);
-    g2_serialize(w2, B2); g16_put_bytes(pr + 64, w2, 32);
-    g1_serialize(w1, Cc); g16_put_bytes(pr + 192, w1, 16);
+    if (which == 0) {
+        uint32_t w1[16]; g1_serialize(w1, ld_g1_jac(sum_g1, 0, row, rows)); g16_put_bytes(pr, w1, 16);
+    } else if (which == 1) {
+        uint32_t w2[32]; g2_serialize(w2, ld_g2_jac(sum_g2, 0, row, rows)); g16_put_bytes(pr + 64, w2, 32);
+    } else {
+        const g1_jac Cc = jac_add(jac_add(ld_g1_jac(sum_g1, 2, row, rows), ld_g1_jac(tmp_g1, 0, row, rows)), ld_g1_jac(tmp_g1, 1, row, rows));
+        uint32_t w1[16]; g1_serialize(w1, Cc); g16_put_bytes(pr + 192, w1, 16);
+    }
 }
 
 }  // namespace zkp

@@ -13,7 +13,7 @@ static constexpr int TB = 256;       // threads per block for (i, proof) grids
 // ds_write) while the current window's point additions run; one barrier per window (after the issuing waves'
 // vmcnt(0)) publishes it.
 template <class T>
-__global__ void __launch_bounds__(MSM_TB) k_msm_dma(MsmView m, uint32_t ngroups, uint32_t nblocks) {
+__global__ void __launch_bounds__(MSM_TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint32_t ngroups, uint32_t nblocks) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins: keep the host-side stub instantiation empty
     constexpr uint32_t SUB_W = NENT * T::AFF_W, SUB_V4 = SUB_W / 4;
     __shared__ uint4 lds4[2][SUB_V4];

@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(TW) k_encode(ReduceView R, const uint32_t* sum
 //   XCD   : workgroups that share a chunk (hence the same sub-tables) are mapped onto the same XCD so the sub-table
 //           stays in that XCD's 4 MB L2 (blocks b and b+8 share an XCD).
 struct EdMsm {      // edwards25519 affine-Niels tables, extended-coordinate accumulator (Bulletproofs path)
-    static constexpr uint32_t AFF_W = NIELS_W, ACC_W = GE_W;
+    static constexpr uint32_t AFF_W = NIELS_W, ACC_W = GE_W, MIN_WAVES = 4;
     using Acc = ge;
     static __device__ __forceinline__ Acc identity() { return ge_identity(); }
     static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) { return msm_accumulate_digit(acc, d, subtab); }
