@@ -26,8 +26,7 @@ struct FrParams {
 };
 
 template <class P> struct Fp { uint32_t v[8]; };
-using fq = Fp<FqParams>;
-using fr = Fp<FrParams>;
+using fr = Fp<FrParams>;     // the base field Fq has its own unsaturated representation: bn254_fq.h
 
 template <class P> ZKP_HD inline Fp<P> fp_zero() { Fp<P> r; ZKP_UNROLL for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
 template <class P> ZKP_HD inline Fp<P> fp_one() { Fp<P> r; ZKP_UNROLL for (int i = 0; i < 8; i++) r.v[i] = P::r1(i); return r; }

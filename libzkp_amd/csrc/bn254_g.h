@@ -4,45 +4,48 @@
 // Replaces ark-ec's short_weierstrass Projective/Affine for ark-bn254 (used via ark-groth16 at
 // /root/reference/src/backend/snark.rs:364,442); serialisation follows ark-serialize's uncompressed form.
 #pragma once
-#include "bn254_fp.h"
+#include "bn254_fq.h"
 
 namespace zkp {
 
 struct fq2 { fq c0, c1; };
 
 // ---- uniform field interface so the point formulas are written once
-ZKP_HD inline fq f_add(const fq& a, const fq& b) { return fp_add(a, b); }
-ZKP_HD inline fq f_sub(const fq& a, const fq& b) { return fp_sub(a, b); }
-ZKP_HD inline fq f_mul(const fq& a, const fq& b) { return fp_mul(a, b); }
-ZKP_HD inline fq f_sq(const fq& a) { return fp_sq(a); }
-ZKP_HD inline fq f_neg(const fq& a) { return fp_neg(a); }
-ZKP_HD inline fq f_dbl(const fq& a) { return fp_dbl(a); }
-ZKP_HD inline bool f_is_zero(const fq& a) { return fp_is_zero(a); }
-ZKP_HD inline fq f_select(bool c, const fq& a, const fq& b) { return fp_select(c, a, b); }
-ZKP_HD inline void f_set_zero(fq& a) { a = fp_zero<FqParams>(); }
-ZKP_HD inline void f_set_one(fq& a) { a = fp_one<FqParams>(); }
-ZKP_HD inline fq f_inv(const fq& a) { return fp_inv(a); }
+// Fq through its "safe" operations (every result < 3p, carried); the MSM inner loop uses the lazy forms directly (g1_madd_lazy)
+ZKP_HD inline fq f_add(const fq& a, const fq& b) { return fq_add(a, b); }
+ZKP_HD inline fq f_sub(const fq& a, const fq& b) { return fq_sub(a, b); }
+ZKP_HD inline fq f_mul(const fq& a, const fq& b) { return fq_mul(a, b); }
+ZKP_HD inline fq f_sq(const fq& a) { return fq_sq(a); }
+ZKP_HD inline fq f_neg(const fq& a) { return fq_neg(a); }
+ZKP_HD inline fq f_dbl(const fq& a) { return fq_dbl(a); }
+ZKP_HD inline bool f_is_zero(const fq& a) { return fq_is_zero(a); }
+ZKP_HD inline fq f_select(bool c, const fq& a, const fq& b) { return fq_select(c, a, b); }
+ZKP_HD inline void f_set_zero(fq& a) { a = fq_zero(); }
+ZKP_HD inline void f_set_one(fq& a) { a = fq_one(); }
+ZKP_HD inline fq f_inv(const fq& a) { return fq_inv(a); }
 
-ZKP_HD inline fq2 f_add(const fq2& a, const fq2& b) { return fq2{fp_add(a.c0, b.c0), fp_add(a.c1, b.c1)}; }
-ZKP_HD inline fq2 f_sub(const fq2& a, const fq2& b) { return fq2{fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; }
-ZKP_HD inline fq2 f_neg(const fq2& a) { return fq2{fp_neg(a.c0), fp_neg(a.c1)}; }
-ZKP_HD inline fq2 f_dbl(const fq2& a) { return fq2{fp_dbl(a.c0), fp_dbl(a.c1)}; }
-ZKP_HD inline fq2 f_mul(const fq2& a, const fq2& b) {            // Karatsuba, u^2 = -1
-    const fq t0 = fp_mul(a.c0, b.c0), t1 = fp_mul(a.c1, b.c1);
-    const fq t2 = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
-    return fq2{fp_sub(t0, t1), fp_sub(fp_sub(t2, t0), t1)};
+ZKP_HD inline fq2 f_add(const fq2& a, const fq2& b) { return fq2{fq_add(a.c0, b.c0), fq_add(a.c1, b.c1)}; }
+ZKP_HD inline fq2 f_sub(const fq2& a, const fq2& b) { return fq2{fq_sub(a.c0, b.c0), fq_sub(a.c1, b.c1)}; }
+ZKP_HD inline fq2 f_neg(const fq2& a) { return fq2{fq_neg(a.c0), fq_neg(a.c1)}; }
+ZKP_HD inline fq2 f_dbl(const fq2& a) { return fq2{fq_dbl(a.c0), fq_dbl(a.c1)}; }
+// Karatsuba, u^2 = -1.  Inputs safe (< 4p, carried); the three products take lazily added operands (< 8p, limbs < 2^27);
+// c0 = t0 - t1 + 4p, c1 = t2 - t0 - t1 + 8p are reduced once each.
+ZKP_HD inline fq2 f_mul(const fq2& a, const fq2& b) {
+    const fq t0 = fq_mul(a.c0, b.c0), t1 = fq_mul(a.c1, b.c1);
+    const fq t2 = fq_mul(fq_add_l(a.c0, a.c1), fq_add_l(b.c0, b.c1));
+    return fq2{fq_reduce_weak(fq_sub_k4(t0, t1)), fq_reduce_weak(fq_sub_k8(t2, fq_add_l(t0, t1)))};
 }
 ZKP_HD inline fq2 f_sq(const fq2& a) {                           // (a0+a1)(a0-a1), 2 a0 a1
-    const fq t = fp_mul(a.c0, a.c1);
-    return fq2{fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_dbl(t)};
+    const fq t = fq_mul(a.c0, a.c1);
+    return fq2{fq_reduce_weak(fq_mul(fq_add_l(a.c0, a.c1), fq_sub_k4(a.c0, a.c1))), fq_reduce_weak(fq_dbl_l(t))};
 }
-ZKP_HD inline bool f_is_zero(const fq2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
-ZKP_HD inline fq2 f_select(bool c, const fq2& a, const fq2& b) { return fq2{fp_select(c, a.c0, b.c0), fp_select(c, a.c1, b.c1)}; }
-ZKP_HD inline void f_set_zero(fq2& a) { a.c0 = fp_zero<FqParams>(); a.c1 = fp_zero<FqParams>(); }
-ZKP_HD inline void f_set_one(fq2& a) { a.c0 = fp_one<FqParams>(); a.c1 = fp_zero<FqParams>(); }
+ZKP_HD inline bool f_is_zero(const fq2& a) { return fq_is_zero(a.c0) && fq_is_zero(a.c1); }
+ZKP_HD inline fq2 f_select(bool c, const fq2& a, const fq2& b) { return fq2{fq_select(c, a.c0, b.c0), fq_select(c, a.c1, b.c1)}; }
+ZKP_HD inline void f_set_zero(fq2& a) { a.c0 = fq_zero(); a.c1 = fq_zero(); }
+ZKP_HD inline void f_set_one(fq2& a) { a.c0 = fq_one(); a.c1 = fq_zero(); }
 ZKP_HD inline fq2 f_inv(const fq2& a) {
-    const fq d = fp_inv(fp_add(fp_sq(a.c0), fp_sq(a.c1)));
-    return fq2{fp_mul(a.c0, d), fp_neg(fp_mul(a.c1, d))};
+    const fq d = fq_inv(fq_add(fq_sq(a.c0), fq_sq(a.c1)));
+    return fq2{fq_reduce_weak(fq_mul(a.c0, d)), fq_neg(fq_reduce_weak(fq_mul(a.c1, d)))};
 }
 
 template <class F> struct Aff { F x, y; };            // never the point at infinity (table entries, generators)
@@ -78,6 +81,40 @@ template <class F> ZKP_HD inline Jac<F> jac_madd(const Jac<F>& p, const Aff<F>& 
     r.X = f_sub(f_sub(f_sq(rr), J), f_dbl(V));
     r.Y = f_sub(f_mul(rr, f_sub(V, r.X)), f_dbl(f_mul(p.Y, J)));
     r.Z = f_sub(f_sub(f_sq(f_add(p.Z, H)), Z1Z1), HH);
+    return r;
+}
+
+// madd-2007-bl without the exceptional-case branches, for the MSM inner loop: the accumulator starts from a fixed offset
+// point (never infinity) and meeting +-(table entry) would need a discrete-log relation between key points and the
+// offset (probability ~2^-250); H = 0 then collapses to Z3 = 0 rather than to wrong finite coordinates.
+template <class F> ZKP_HD inline Jac<F> jac_madd_nocheck(const Jac<F>& p, const Aff<F>& q) {
+    const F Z1Z1 = f_sq(p.Z);
+    const F U2 = f_mul(q.x, Z1Z1), S2 = f_mul(f_mul(q.y, p.Z), Z1Z1);
+    const F H = f_sub(U2, p.X), rr = f_dbl(f_sub(S2, p.Y));
+    const F HH = f_sq(H), I = f_dbl(f_dbl(HH)), J = f_mul(H, I), V = f_mul(p.X, I);
+    Jac<F> r;
+    r.X = f_sub(f_sub(f_sq(rr), J), f_dbl(V));
+    r.Y = f_sub(f_mul(rr, f_sub(V, r.X)), f_dbl(f_mul(p.Y, J)));
+    r.Z = f_sub(f_sub(f_sq(f_add(p.Z, H)), Z1Z1), HH);
+    return r;
+}
+
+// The G1 MSM inner loop: madd-2007-bl on lazily reduced limbs (bounds proved in tests/test_fq_bounds.py).
+// p = (X1, Y1, Z1) safe (< 4p... in fact < 3p, carried); q affine with safe coordinates (table entries are canonical).
+// With s = S2 - Y1 (so r = 2s):  X3 = 4 s^2 - J - 2V ;  Y3 = 2 (s (V - X3) - Y1 J) ;  Z3 = (Z1 + H)^2 - Z1Z1 - HH.
+ZKP_HD inline Jac<fq> g1_madd_lazy(const Jac<fq>& p, const Aff<fq>& q) {
+    const fq Z1Z1 = fq_sq(p.Z);
+    const fq U2 = fq_mul(q.x, Z1Z1), S2 = fq_mul(fq_mul(q.y, p.Z), Z1Z1);
+    const fq H = fq_sub_k4(U2, p.X), sv = fq_sub_k4(S2, p.Y);           // < 7p, limbs < 2^27.6
+    const fq HH = fq_sq(H);
+    const fq I = fq_dbl_l(fq_dbl_l(HH));                                 // 4 HH, limbs < 2^28
+    const fq J = fq_mul(H, I), V = fq_mul(p.X, I);
+    const fq ss = fq_sq(sv);
+    Jac<fq> r;
+    r.X = fq_reduce_weak(fq_sub_k8(fq_sub_k4(fq_dbl_l(fq_dbl_l(ss)), J), fq_dbl_l(V)));
+    const fq t = fq_sub_k4(fq_mul(sv, fq_sub_k4(V, r.X)), fq_mul(p.Y, J));
+    r.Y = fq_reduce_weak(fq_dbl_l(t));
+    r.Z = fq_reduce_weak(fq_sub_k4(fq_sub_k4(fq_sq(fq_add_l(p.Z, H)), Z1Z1), HH));
     return r;
 }
 
@@ -131,13 +168,13 @@ ZKP_HD inline bool fq_raw_gt_half(const uint32_t w[8]) {   // w > (p-1)/2  <=>  
 ZKP_HD inline void g1_serialize(uint32_t out[16], const g1_jac& p) {
     g1_aff a;
     if (!jac_to_aff(a, p)) { for (int i = 0; i < 16; i++) out[i] = 0; out[15] = 0x40000000u; return; }
-    fp_to_raw(out, a.x); fp_to_raw(out + 8, a.y);
+    fq_to_raw(out, a.x); fq_to_raw(out + 8, a.y);
     if (fq_raw_gt_half(out + 8)) out[15] |= 0x80000000u;
 }
 ZKP_HD inline void g2_serialize(uint32_t out[32], const g2_jac& p) {
     g2_aff a;
     if (!jac_to_aff(a, p)) { for (int i = 0; i < 32; i++) out[i] = 0; out[31] = 0x40000000u; return; }
-    fp_to_raw(out, a.x.c0); fp_to_raw(out + 8, a.x.c1); fp_to_raw(out + 16, a.y.c0); fp_to_raw(out + 24, a.y.c1);
+    fq_to_raw(out, a.x.c0); fq_to_raw(out + 8, a.x.c1); fq_to_raw(out + 16, a.y.c0); fq_to_raw(out + 24, a.y.c1);
     uint32_t nz = 0; for (int i = 0; i < 8; i++) nz |= out[24 + i];
     const bool larger = nz ? fq_raw_gt_half(out + 24) : fq_raw_gt_half(out + 16);   // order: c1 first, then c0
     if (larger) out[31] |= 0x80000000u;

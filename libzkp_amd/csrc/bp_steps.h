@@ -162,6 +162,8 @@ struct MsmView {
     const uint16_t* chunk_win0;  // [nchunks] first window inside that slot (chunks are window-granular)
     const uint16_t* chunk_nwin;  // [nchunks] number of (slot, window) steps in the chunk
     uint32_t* partial;           // [nchunks][40][rows]
+    const uint32_t* acc_init;    // optional [ACC_W]: every chunk's accumulator starts from this point (Weierstrass MSMs: a
+                                 // fixed offset point so the unchecked mixed addition never sees infinity); nullptr = identity
 };
 ZKP_HD inline void msm_chunk_ref(const MsmView& m, uint32_t chunk, uint32_t row) {
     ge acc = ge_identity();
@@ -183,6 +185,7 @@ struct ReduceView {
     uint32_t* enc;                       // [ntargets][8][rows]
     const uint64_t* out_off;             // optional [rows]: also write target 0's 32 bytes to out + out_off[row]
     uint8_t* out;
+    const uint32_t* corr;                // optional [ntargets][ACC_W]: point added to each target's sum (-(#chunks) * offset)
 };
 ZKP_HD inline void reduce_encode_thread(const ReduceView& r, uint32_t target, uint32_t row) {
     const uint32_t c0 = r.target_chunk_begin[target], c1 = r.target_chunk_begin[target + 1];

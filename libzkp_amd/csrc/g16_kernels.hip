@@ -3,28 +3,28 @@
 #include "msm_kernel.h"
 
 struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b1/h/l queries)
-    static constexpr uint32_t AFF_W = 16, ACC_W = 24, MIN_WAVES = 3;
+    static constexpr uint32_t AFF_W = 20, ACC_W = G1_JAC_W, MIN_WAVES = 3;
     using Acc = g1_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq>(); }
     static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
         const uint32_t* e = subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W;
-        g1_aff q; ZKP_UNROLL for (int k = 0; k < 8; k++) { q.x.v[k] = e[k]; q.y.v[k] = e[8 + k]; }
-        q.y = fp_select(d < 0, fp_neg(q.y), q.y);
-        return jac_madd(acc, q);
+        g1_aff q; ZKP_UNROLL for (int k = 0; k < 10; k++) { q.x.v[k] = e[k]; q.y.v[k] = e[10 + k]; }
+        q.y = fq_select(d < 0, fq_sub_k4(fq_zero(), q.y), q.y);          // 4p - y: limbs < 2^27, fine as a product operand
+        return g1_madd_lazy(acc, q);
     }
     static __device__ __forceinline__ void store(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const Acc& a) { st_g1_jac(p, idx, row, rows, a); }
     static __device__ __forceinline__ Acc load(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) { return ld_g1_jac(p, idx, row, rows); }
     static __device__ __forceinline__ Acc add(const Acc& a, const Acc& b) { return jac_add(a, b); }
 };
 struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
-    static constexpr uint32_t AFF_W = 32, ACC_W = 48, MIN_WAVES = 2;
+    static constexpr uint32_t AFF_W = 40, ACC_W = G2_JAC_W, MIN_WAVES = 2;
     using Acc = g2_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq2>(); }
     static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
         const uint32_t* e = subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W;
-        g2_aff q; ZKP_UNROLL for (int k = 0; k < 8; k++) { q.x.c0.v[k] = e[k]; q.x.c1.v[k] = e[8 + k]; q.y.c0.v[k] = e[16 + k]; q.y.c1.v[k] = e[24 + k]; }
+        g2_aff q; ZKP_UNROLL for (int k = 0; k < 10; k++) { q.x.c0.v[k] = e[k]; q.x.c1.v[k] = e[10 + k]; q.y.c0.v[k] = e[20 + k]; q.y.c1.v[k] = e[30 + k]; }
         q.y = f_select(d < 0, f_neg(q.y), q.y);
-        return jac_madd(acc, q);
+        return jac_madd_nocheck(acc, q);
     }
     static __device__ __forceinline__ void store(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const Acc& a) { st_g2_jac(p, idx, row, rows, a); }
     static __device__ __forceinline__ Acc load(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) { return ld_g2_jac(p, idx, row, rows); }
@@ -103,8 +103,8 @@ template __global__ void k_msm_dma<G1Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_msm_dma<G2Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_sum_t<G1Msm>(ReduceView, uint32_t*);
 template __global__ void k_sum_t<G2Msm>(ReduceView, uint32_t*);
-template __global__ void k_g16_build_table<fq, 16>(const uint32_t*, uint32_t, uint32_t*);
-template __global__ void k_g16_build_table<fq2, 32>(const uint32_t*, uint32_t, uint32_t*);
+template __global__ void k_g16_build_table<fq, 20>(const uint32_t*, uint32_t, uint32_t*);
+template __global__ void k_g16_build_table<fq2, 40>(const uint32_t*, uint32_t, uint32_t*);
 
 // ================================================================================================ launchers
 void g16_launch_witness(const G16View& V, hipStream_t st) { k_g16_witness<<<(V.rows + TW - 1) / TW, TW, 0, st>>>(V); }
@@ -123,8 +123,8 @@ void g16_launch_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* 
 void g16_launch_mimc(const uint64_t* values, uint32_t n, const uint32_t* mimc_c, uint8_t* out, hipStream_t st) { k_mimc_commit<<<(n + TW - 1) / TW, TW, 0, st>>>(values, n, mimc_c, out); }
 void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uint32_t* table, hipStream_t st) {
     const uint32_t threads = nslots * NWIN;
-    if (!g2) k_g16_build_table<fq, 16><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table);
-    else k_g16_build_table<fq2, 32><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table);
+    if (!g2) k_g16_build_table<fq, 20><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table);
+    else k_g16_build_table<fq2, 40><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table);
 }
 void g16_launch_msm(bool g2, const MsmView& m, hipStream_t st) {
     const uint32_t ngroups = (m.rows + MSM_TB - 1) / MSM_TB, nblocks = m.nchunks * ngroups, grid = ((nblocks + 7) / 8) * 8;

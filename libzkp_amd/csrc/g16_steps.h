@@ -228,31 +228,31 @@ ZKP_HD inline void g16_qap_proof(const G16View& V, const G16Circuit& C, const G1
 }
 
 // ---- final assembly.  thread = proof.  sums: [4 targets][words][rows] Jacobian sums A (G1), B1 (G1), Cp (G1), B2 (G2)
+// Jacobian points in global memory: ten 26-bit limbs per Fq coordinate, word-major ([word][row]) so that lane = row is coalesced
+#define G1_JAC_W 30
+#define G2_JAC_W 60
+ZKP_HD inline fq ld_fq_col(const uint32_t* q, uint32_t rows) { fq r; ZKP_UNROLL for (int k = 0; k < 10; k++) r.v[k] = q[(size_t)k * rows]; return r; }
+ZKP_HD inline void st_fq_col(uint32_t* q, uint32_t rows, const fq& a) { ZKP_UNROLL for (int k = 0; k < 10; k++) q[(size_t)k * rows] = a.v[k]; }
 ZKP_HD inline g1_jac ld_g1_jac(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) {
-    g1_jac r; const uint32_t* q = p + (size_t)idx * 24 * rows + row;
-    ZKP_UNROLL for (int k = 0; k < 8; k++) { r.X.v[k] = q[(size_t)k * rows]; r.Y.v[k] = q[(size_t)(8 + k) * rows]; r.Z.v[k] = q[(size_t)(16 + k) * rows]; }
+    const uint32_t* q = p + (size_t)idx * G1_JAC_W * rows + row; const size_t s = (size_t)10 * rows;
+    g1_jac r; r.X = ld_fq_col(q, rows); r.Y = ld_fq_col(q + s, rows); r.Z = ld_fq_col(q + 2 * s, rows);
     return r;
 }
 ZKP_HD inline void st_g1_jac(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const g1_jac& g) {
-    uint32_t* q = p + (size_t)idx * 24 * rows + row;
-    ZKP_UNROLL for (int k = 0; k < 8; k++) { q[(size_t)k * rows] = g.X.v[k]; q[(size_t)(8 + k) * rows] = g.Y.v[k]; q[(size_t)(16 + k) * rows] = g.Z.v[k]; }
+    uint32_t* q = p + (size_t)idx * G1_JAC_W * rows + row; const size_t s = (size_t)10 * rows;
+    st_fq_col(q, rows, g.X); st_fq_col(q + s, rows, g.Y); st_fq_col(q + 2 * s, rows, g.Z);
 }
 ZKP_HD inline g2_jac ld_g2_jac(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) {
-    g2_jac r; const uint32_t* q = p + (size_t)idx * 48 * rows + row;
-    ZKP_UNROLL for (int k = 0; k < 8; k++) {
-        r.X.c0.v[k] = q[(size_t)k * rows]; r.X.c1.v[k] = q[(size_t)(8 + k) * rows];
-        r.Y.c0.v[k] = q[(size_t)(16 + k) * rows]; r.Y.c1.v[k] = q[(size_t)(24 + k) * rows];
-        r.Z.c0.v[k] = q[(size_t)(32 + k) * rows]; r.Z.c1.v[k] = q[(size_t)(40 + k) * rows];
-    }
+    const uint32_t* q = p + (size_t)idx * G2_JAC_W * rows + row; const size_t s = (size_t)10 * rows;
+    g2_jac r;
+    r.X.c0 = ld_fq_col(q, rows); r.X.c1 = ld_fq_col(q + s, rows); r.Y.c0 = ld_fq_col(q + 2 * s, rows); r.Y.c1 = ld_fq_col(q + 3 * s, rows);
+    r.Z.c0 = ld_fq_col(q + 4 * s, rows); r.Z.c1 = ld_fq_col(q + 5 * s, rows);
     return r;
 }
 ZKP_HD inline void st_g2_jac(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const g2_jac& g) {
-    uint32_t* q = p + (size_t)idx * 48 * rows + row;
-    ZKP_UNROLL for (int k = 0; k < 8; k++) {
-        q[(size_t)k * rows] = g.X.c0.v[k]; q[(size_t)(8 + k) * rows] = g.X.c1.v[k];
-        q[(size_t)(16 + k) * rows] = g.Y.c0.v[k]; q[(size_t)(24 + k) * rows] = g.Y.c1.v[k];
-        q[(size_t)(32 + k) * rows] = g.Z.c0.v[k]; q[(size_t)(40 + k) * rows] = g.Z.c1.v[k];
-    }
+    uint32_t* q = p + (size_t)idx * G2_JAC_W * rows + row; const size_t s = (size_t)10 * rows;
+    st_fq_col(q, rows, g.X.c0); st_fq_col(q + s, rows, g.X.c1); st_fq_col(q + 2 * s, rows, g.Y.c0); st_fq_col(q + 3 * s, rows, g.Y.c1);
+    st_fq_col(q + 4 * s, rows, g.Z.c0); st_fq_col(q + 5 * s, rows, g.Z.c1);
 }
 // C = Cp + s*A + r*B1 (Cp already contains l_aux, h and -rs*delta); proof = A || B2 || C  (snark.rs:369-373).
 // Split over lanes: thread (which, row) of step_g16_cparts computes s*A (which = 0) or r*B1 (which = 1); thread

@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(MSM_TB, T::MIN_WAVES) k_msm_dma(MsmView m, uin
     const uint32_t row = group * MSM_TB + tid;
     const bool active = row < m.rows;
     uint32_t s = m.chunk_begin[chunk], w = m.chunk_win0[chunk], left = m.chunk_nwin[chunk], cur = 0;
-    typename T::Acc acc = T::identity();
+    typename T::Acc acc = m.acc_init ? T::load(m.acc_init, 0, 0, 1) : T::identity();
 #define ZKP_MSM_DMA(buf_, base_, win_)                                                                              \
     do {                                                                                                            \
         const uint4* src_ = reinterpret_cast<const uint4*>(m.table + ((size_t)(base_) * NWIN + (win_)) * SUB_W);     \
@@ -88,6 +88,9 @@ __global__ void __launch_bounds__(TW) k_sum_t(ReduceView R, uint32_t* sums) {
         __syncthreads();
     }
     (void)mine;
-    if (grp == 0 && active) T::store(sums, target, row, R.rows, acc);
+    if (grp == 0 && active) {
+        if (R.corr) acc = T::add(acc, T::load(R.corr, target, 0, 1));
+        T::store(sums, target, row, R.rows, acc);
+    }
 }
 

@@ -329,7 +329,7 @@ int ensure_workspace(SubBatch& sb, uint32_t M, uint32_t C) {
 
 int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32_t* partial, hipStream_t st) {
     MsmView m; m.rows = rows; m.nslots = D.nslots; m.nchunks = D.nchunks; m.table = g.d_table; m.digits = digits;
-    m.slot_base = D.slot_base; m.slot_scalar = nullptr; m.slot_nwin = D.slot_nwin; m.chunk_begin = D.chunk_begin; m.chunk_win0 = D.chunk_win0; m.chunk_nwin = D.chunk_nwin; m.partial = partial;
+    m.slot_base = D.slot_base; m.slot_scalar = nullptr; m.slot_nwin = D.slot_nwin; m.chunk_begin = D.chunk_begin; m.chunk_win0 = D.chunk_win0; m.chunk_nwin = D.chunk_nwin; m.partial = partial; m.acc_init = nullptr;
     const uint32_t ngroups = (rows + MSM_TB - 1) / MSM_TB, nblocks = D.nchunks * ngroups;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -346,7 +346,7 @@ int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32
 }
 int launch_reduce(const DevLayout& D, uint32_t rows, const uint32_t* partial, uint32_t* sums, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
     ReduceView R; R.rows = rows; R.ntargets = D.ntargets; R.partial = partial; R.target_chunk_begin = D.target_chunk_begin;
-    R.enc = enc; R.out_off = out_off; R.out = out;
+    R.enc = enc; R.out_off = out_off; R.out = out; R.corr = nullptr;
     k_sum_t<EdMsm><<<dim3((rows + 7) / 8, D.ntargets), TW, 0, st>>>(R, sums);
     k_encode<<<dim3((rows + TW - 1) / TW, D.ntargets), TW, 0, st>>>(R, sums);
     return 0;

@@ -9,12 +9,50 @@ template <class P> static void fp_op(int op, const uint32_t a[8], const uint32_t
                   case 4: r = fp_inv(x); break; default: r = fp_add(fp_add(x, y), fp_sub(y, x)); r = fp_mul(r, fp_sub(x, fp_add(y, y))); }
     fp_to_raw(out, r);
 }
-static g1_aff load_g1(const uint32_t w[16]) { return g1_aff{fp_from_raw<FqParams>(w), fp_from_raw<FqParams>(w + 8)}; }
+static void fq_op(int op, const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) {
+    fq x = fq_from_raw(a), y = fq_from_raw(b), r;
+    switch (op) { case 0: r = fq_mul(x, y); break; case 1: r = fq_add(x, y); break; case 2: r = fq_sub(x, y); break; case 3: r = fq_neg(x); break;
+                  case 4: r = fq_inv(x); break; default: r = fq_add(fq_add(x, y), fq_sub(y, x)); r = fq_mul(r, fq_sub(x, fq_add(y, y))); }
+    fq_to_raw(out, r);
+}
+static g1_aff load_g1(const uint32_t w[16]) { return g1_aff{fq_from_raw(w), fq_from_raw(w + 8)}; }
 static g2_aff load_g2(const uint32_t w[32]) {
-    return g2_aff{fq2{fp_from_raw<FqParams>(w), fp_from_raw<FqParams>(w + 8)}, fq2{fp_from_raw<FqParams>(w + 16), fp_from_raw<FqParams>(w + 24)}};
+    return g2_aff{fq2{fq_from_raw(w), fq_from_raw(w + 8)}, fq2{fq_from_raw(w + 16), fq_from_raw(w + 24)}};
 }
 extern "C" {
-void emul_fq_op(int op, const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) { fp_op<FqParams>(op, a, b, out); }
+void emul_fq_op(int op, const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) { fq_op(op, a, b, out); }
+// lazy-limb forms on loose inputs: x' = x + ka*p (limb-wise, uncarried), y' = y + kb*p; op 0: mul, 1: (x'+y') * (x' + 4p - y'), 2: reduce_weak(x' + 8p - y'),
+// 3: to_raw(x') directly, 4: sq(x' + 16p - 2^2 y) with y canonical
+void emul_fq_lazy(int op, const uint32_t a[8], const uint32_t b[8], int ka, int kb, uint32_t out[8]) {
+    fq x = fq_from_raw(a), y = fq_from_raw(b), pl, r;
+    for (int i = 0; i < 10; i++) pl.v[i] = fq_pl(i);
+    const fq y0 = y;
+    for (int i = 0; i < ka; i++) x = fq_add_l(x, pl);
+    for (int i = 0; i < kb; i++) y = fq_add_l(y, pl);
+    switch (op) { case 0: r = fq_mul(x, y); break; case 1: r = fq_mul(fq_add_l(x, y), fq_sub_k4(x, fq_reduce_weak(y))); break;
+                  case 2: r = fq_reduce_weak(fq_sub_k8(x, fq_carry(y))); break; case 3: r = x; break;
+                  default: r = fq_sq(fq_sub_k16(x, fq_dbl_l(fq_dbl_l(y0)))); }
+    fq_to_raw(out, r);
+}
+// the MSM inner loop as the kernels run it: acc = O; acc += sign_i * T_i with the lazy mixed addition; out = serialize(acc)
+void emul_g1_lazy_chain(const uint32_t o[16], const uint32_t* pts, const int* signs, int n, uint32_t out[16]) {
+    g1_jac acc = jac_dbl(jac_from_aff(load_g1(o)));                 // Z != 1
+    for (int i = 0; i < n; i++) {
+        g1_aff q = load_g1(pts + 16 * i);
+        q.y = fq_select(signs[i] < 0, fq_sub_k4(fq_zero(), q.y), q.y);
+        acc = g1_madd_lazy(acc, q);
+    }
+    g1_serialize(out, acc);
+}
+void emul_g2_lazy_chain(const uint32_t o[32], const uint32_t* pts, const int* signs, int n, uint32_t out[32]) {
+    g2_jac acc = jac_dbl(jac_from_aff(load_g2(o)));
+    for (int i = 0; i < n; i++) {
+        g2_aff q = load_g2(pts + 32 * i);
+        q.y = f_select(signs[i] < 0, f_neg(q.y), q.y);
+        acc = jac_madd_nocheck(acc, q);
+    }
+    g2_serialize(out, acc);
+}
 void emul_fr_op(int op, const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) { fp_op<FrParams>(op, a, b, out); }
 void emul_fr_from_wide(const uint32_t w[16], uint32_t out[8]) { fp_to_raw(out, fp_from_wide<FrParams>(w)); }
 // serialize(k1*P + k2*Q) with P, Q affine (raw coords); uses madd for the first term path, add, dbl via jac_mul_raw

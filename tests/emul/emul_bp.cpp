@@ -19,12 +19,12 @@ struct DevLayout { MsmLayout L; };
 static void run_msm(const MsmLayout& L, uint32_t rows, const uint32_t* digits, std::vector<uint32_t>& partial) {
     MsmView m; m.rows = rows; m.nslots = L.nslots(); m.nchunks = L.nchunks(); m.table = g_table.data(); m.digits = digits;
     m.slot_base = L.slot_base.data(); m.slot_scalar = nullptr; m.slot_nwin = L.slot_nwin.data(); m.chunk_begin = L.chunk_begin.data(); m.chunk_win0 = L.chunk_win0.data(); m.chunk_nwin = L.chunk_nwin.data();
-    partial.assign((size_t)L.nchunks() * GE_W * rows, 0); m.partial = partial.data();
+    partial.assign((size_t)L.nchunks() * GE_W * rows, 0); m.partial = partial.data(); m.acc_init = nullptr;
     for (uint32_t c = 0; c < L.nchunks(); c++) for (uint32_t row = 0; row < rows; row++) msm_chunk_ref(m, c, row);
 }
 static void run_reduce(const MsmLayout& L, uint32_t rows, const std::vector<uint32_t>& partial, uint32_t* enc, const uint64_t* out_off, uint8_t* out) {
     ReduceView r; r.rows = rows; r.ntargets = L.ntargets(); r.partial = partial.data(); r.target_chunk_begin = L.target_chunk_begin.data();
-    r.enc = enc; r.out_off = out_off; r.out = out;
+    r.enc = enc; r.out_off = out_off; r.out = out; r.corr = nullptr;
     for (uint32_t t = 0; t < L.ntargets(); t++) for (uint32_t row = 0; row < rows; row++) reduce_encode_thread(r, t, row);
 }
 

@@ -70,6 +70,47 @@ def test_groups_and_serialisation(libs):
         assert I(o32).to_bytes(128, "little") == b.ser_g2(b.G2C.mul_pt(b.G2, s) if s else None)
 
 
+def test_fq_lazy_limbs(libs):
+    """Unsaturated Fq: products and weak reductions on uncarried, loosely reduced inputs (bn254_fq.h bounds vocabulary)."""
+    lib, _ = libs
+    rnd = random.Random(11)
+    out = (ctypes.c_uint32 * 8)()
+    p = b.P
+    edge = [0, 1, p - 1, p - 2, (p - 1) // 2, 2**253, 2**254 - 1]
+    for trial in range(300):
+        a = edge[trial % len(edge)] if trial < 3 * len(edge) else rnd.randrange(p)
+        c = edge[(trial // len(edge)) % len(edge)] if trial < 3 * len(edge) else rnd.randrange(p)
+        ka, kb = rnd.randrange(0, 7), rnd.randrange(0, 7)
+        for op, f in ((0, a * c), (1, (a + c) * (a - c)), (2, a - c), (3, a), (4, (a - 4 * c) ** 2)):
+            lib.emul_fq_lazy(op, W(a), W(c), ka if op != 4 else min(ka, 3), kb if op != 2 else min(kb, 5), out)
+            assert I(out) == f % p, (op, trial)
+
+
+def test_msm_inner_loop_lazy(libs):
+    """The unchecked, lazily reduced mixed additions of the MSM kernels, started from an offset point with Z != 1."""
+    lib, _ = libs
+    rnd = random.Random(13)
+    g1w = lambda pt: [(pt[0] >> (32 * i)) & 0xFFFFFFFF for i in range(8)] + [(pt[1] >> (32 * i)) & 0xFFFFFFFF for i in range(8)]  # noqa: E731
+    def g2w(pt):
+        ws = []
+        for v in (pt[0][0], pt[0][1], pt[1][0], pt[1][1]):
+            ws += [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        return ws
+    n = 40
+    ks = [rnd.randrange(1, b.R) for _ in range(n)]
+    signs = [rnd.choice((-1, 1)) for _ in range(n)]
+    ko = rnd.randrange(1, b.R)
+    total = (2 * ko + sum(s * k for s, k in zip(signs, ks))) % b.R
+    arr = (ctypes.c_int * n)(*signs)
+    o16, o32 = (ctypes.c_uint32 * 16)(), (ctypes.c_uint32 * 32)()
+    pts1 = (ctypes.c_uint32 * (16 * n))(*sum((g1w(b.G1C.mul_pt(b.G1, k)) for k in ks), []))
+    lib.emul_g1_lazy_chain((ctypes.c_uint32 * 16)(*g1w(b.G1C.mul_pt(b.G1, ko))), pts1, arr, n, o16)
+    assert I(o16).to_bytes(64, "little") == b.ser_g1(b.G1C.mul_pt(b.G1, total))
+    pts2 = (ctypes.c_uint32 * (32 * n))(*sum((g2w(b.G2C.mul_pt(b.G2, k)) for k in ks), []))
+    lib.emul_g2_lazy_chain((ctypes.c_uint32 * 32)(*g2w(b.G2C.mul_pt(b.G2, ko))), pts2, arr, n, o32)
+    assert I(o32).to_bytes(128, "little") == b.ser_g2(b.G2C.mul_pt(b.G2, total))
+
+
 def _run(lib, kind, value, the_set, seed):
     nv, m = (334, 512) if kind == 0 else (653, 1024)
     z = np.zeros((nv, 8), dtype=np.uint32)

@@ -1,0 +1,137 @@
+"""Interval-arithmetic proof for the unsaturated BN254 base field (libzkp_amd/csrc/bn254_fq.h) and the lazily reduced
+mixed additions of the Groth16 MSM inner loops (bn254_g.h: g1_madd_lazy, g2_madd_lazy): no 32-bit limb operation and
+no 64-bit column sum overflows, every borrowed-multiple subtraction has a covered subtrahend, and every result handed
+to the next iteration is "safe" again (no GPU).
+
+A tracked value is (limbs, val): inclusive upper bounds of the ten limbs and of the integer value, in units of p/1000."""
+P = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+R_OVER_P = (1 << 260) * 1000 // P            # 84.6 (x1000)
+PL = [(P >> (26 * i)) & 0x3FFFFFF if i < 9 else P >> 234 for i in range(10)]
+M26 = (1 << 26) - 1
+
+
+def header_constants():
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "libzkp_amd", "csrc", "bn254_fq.h")).read()
+    out = {}
+    for name in ("fq_pl", "fq_k4", "fq_k8", "fq_k16", "fq_one_l", "fq_r2_l"):
+        m = re.search(name + r"\(int i\) \{ constexpr uint32_t m\[10\] = \{([^}]*)\}", src)
+        out[name] = [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")]
+    out["n0"] = int(re.search(r"#define ZKP_FQ_N0 (0x[0-9a-f]+)u", src).group(1), 16)
+    out["recip"] = int(re.search(r"#define ZKP_FQ_RECIP (\d+)u", src).group(1))
+    return out
+
+
+C = header_constants()
+
+
+def test_constants():
+    val = lambda l: sum(x << (26 * i) for i, x in enumerate(l))  # noqa: E731
+    assert C["fq_pl"] == PL
+    for n, name in ((4, "fq_k4"), (8, "fq_k8"), (16, "fq_k16")):
+        assert val(C[name]) == n * P
+        assert all(x >= n << 24 for x in C[name][:9]) and all(x < 1 << 32 for x in C[name])
+    assert val(C["fq_one_l"]) == (1 << 260) % P and val(C["fq_r2_l"]) == (1 << 520) % P
+    assert (C["n0"] * P + 1) % (1 << 26) == 0
+    assert C["recip"] == (1 << 266) // P
+
+
+# ---- tracked values
+class V:
+    def __init__(self, limbs, val):
+        self.l, self.val = list(limbs), val
+        assert all(x < 1 << 32 for x in self.l), "limb overflows 32 bits"
+
+
+def carried(val_milli_p):
+    top = (val_milli_p * P // 1000) >> 234
+    return V([M26] * 9 + [top], val_milli_p)
+
+
+SAFE = carried(3000)          # what fq_reduce_weak returns
+CANON = carried(2000)         # table entries: fq_mul outputs < 2p
+
+
+def add_l(a, b):
+    return V([x + y for x, y in zip(a.l, b.l)], a.val + b.val)
+
+
+def dbl_l(a):
+    return add_l(a, a)
+
+
+def sub_k(n, a, b):
+    k = C["fq_k%d" % n]
+    assert all(y <= kk for y, kk in zip(b.l, k)), ("subtrahend limb exceeds borrowed %dp" % n, b.l, k)
+    return V([x + kk for x, kk in zip(a.l, k)], a.val + 1000 * n)
+
+
+def mul(a, b):
+    for col in range(19):
+        acc = sum(a.l[j] * b.l[col - j] for j in range(10) if 0 <= col - j < 10)
+        acc += sum(M26 * PL[col - j] for j in range(10) if 0 <= col - j < 10)
+        assert acc + (1 << 38) < 1 << 64, ("column", col, acc.bit_length())
+    out = a.val * b.val // R_OVER_P + 1000 + 1
+    assert out < 4000, "product leaves the safe range"
+    return carried(out)
+
+
+def sq(a):
+    return mul(a, a)
+
+
+def reduce_weak(a):
+    assert a.val * P // 1000 < 1 << 260
+    assert all(x + (1 << 6) < 1 << 32 for x in a.l)
+    return carried(3000)
+
+
+def carry(a):
+    assert a.val * P // 1000 < 1 << 260 and all(x + (1 << 6) < 1 << 32 for x in a.l)
+    return carried(a.val)
+
+
+def g1_madd_lazy(X1, Y1, Z1, x2, y2):
+    Z1Z1 = sq(Z1)
+    U2, S2 = mul(x2, Z1Z1), mul(mul(y2, Z1), Z1Z1)
+    H, sv = sub_k(4, U2, X1), sub_k(4, S2, Y1)
+    HH = sq(H)
+    I = dbl_l(dbl_l(HH))
+    J, Vv = mul(H, I), mul(X1, I)
+    ss = sq(sv)
+    X3 = reduce_weak(sub_k(8, sub_k(4, dbl_l(dbl_l(ss)), J), dbl_l(Vv)))
+    t = sub_k(4, mul(sv, sub_k(4, Vv, X3)), mul(Y1, J))
+    Y3 = reduce_weak(dbl_l(t))
+    Z3 = reduce_weak(sub_k(4, sub_k(4, sq(add_l(Z1, H)), Z1Z1), HH))
+    return X3, Y3, Z3
+
+
+def test_g1_madd_lazy_is_closed_over_safe_inputs():
+    zero = V([0] * 10, 0)
+    neg_y = sub_k(4, zero, CANON)                       # 4p - y for a negative digit
+    for y2 in (CANON, neg_y):
+        out = g1_madd_lazy(SAFE, SAFE, SAFE, CANON, y2)
+        assert all(o.val <= 3000 and max(o.l[:9]) <= M26 for o in out)
+
+
+def test_reduce_weak_quotient():
+    """q = floor(top * RECIP / 2^32) never exceeds floor(x / p) and leaves x - q p < 3p (exhaustive over the top limb edges)."""
+    import random
+    rnd = random.Random(5)
+    recip = C["recip"]
+    for _ in range(20000):
+        x = rnd.randrange(1 << 260) if rnd.random() < 0.7 else rnd.randrange(64) * P + rnd.choice((0, 1, P - 1, P // 2))
+        x = min(x, (1 << 260) - 1)
+        q = ((x >> 234) * recip) >> 32
+        assert 0 <= x - q * P < 3 * P
+
+
+def test_safe_ops_used_by_generic_point_formulas():
+    """f_add / f_sub / f_dbl (reduce_weak after one limb-wise op) and the Karatsuba Fq2 product on safe inputs."""
+    a = SAFE
+    reduce_weak(add_l(a, a)); reduce_weak(sub_k(8, a, a)); reduce_weak(dbl_l(a))
+    t0, t1 = mul(a, a), mul(a, a)
+    t2 = mul(add_l(a, a), add_l(a, a))
+    reduce_weak(sub_k(4, t0, t1)); reduce_weak(sub_k(8, t2, add_l(t0, t1)))
+    reduce_weak(mul(add_l(a, a), sub_k(4, a, a))); reduce_weak(dbl_l(mul(a, a)))
