@@ -97,6 +97,19 @@ int zkp_hip_snark_commit_value_batch(uint64_t n, const uint64_t* values, uint8_t
 int zkp_hip_prove_equality_batch(uint64_t n, const uint64_t* val1, const uint64_t* val2, const uint8_t* seeds,
                                  uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status);
 
+/* Replaces a loop of proof::improvement_proof::prove_improvement(old, new) (improvement_proof.rs:10-35 ->
+ * StarkBackend::prove / prove_improvement, stark.rs:151-186,216-235; commitment utils/commitment.rs:38-50).
+ * Deterministic (no randomness tape).  Envelope (scheme 5) = 10 + 16 + stark + 32 bytes, where the STARK proof's length
+ * depends on how many of the 32 query positions coincide; stride >= zkp_hip_improvement_max_bytes() (3527).
+ * new <= old -> ZKP_HIP_INVALID_INPUT ("new value must be greater than old value", validation.rs:63-71). */
+uint32_t zkp_hip_improvement_max_bytes(void);
+int zkp_hip_prove_improvement_batch(uint64_t n, const uint64_t* old_values, const uint64_t* new_values,
+                                    uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status);
+/* Same with every pointer a device pointer; launched on `stream` (NULL = the library's stream, synchronised before
+ * return).  Ops with new <= old get out_len = 0. */
+int zkp_hip_prove_improvement_batch_device(uint64_t n, const uint64_t* d_old, const uint64_t* d_new, uint8_t* d_out, uint64_t stride,
+                                           uint32_t* d_out_len, void* stream);
+
 /* Replaces a loop of proof::set_membership::prove_membership(value, set) (set_membership.rs:12-38 ->
  * SnarkBackend::prove_membership_zk, snark.rs:405-452).  sets = all ops' sets concatenated, set_counts[i] <= 64.
  * Envelope (scheme 4) = 10 + 4 + 8*len + 256 + 32 bytes; stride >= the largest. */

@@ -1,12 +1,13 @@
-"""libzkp_amd -- MI355X-native proving backend for libzkp's Bulletproofs hot path.
+"""libzkp_amd -- MI355X-native proving backend for libzkp's proving hot path.
 
 Python surface mirroring the names of the reference's PyO3 module (/root/reference/src/python_api.rs:110-164)
-for the path in scope: range proofs and the batch driver.  Everything is computed by the
+for the path in scope: the six prove_* operations and the batch driver.  Everything is computed by the
 HIP library behind the C ABI of include/libzkp_hip.h; there is no CPU fallback.
 """
 from .api import (  # noqa: F401
     prove_range, prove_range_batch, prove_threshold, prove_threshold_batch, prove_consistency, prove_consistency_batch,
-    prove_equality, prove_equality_batch, prove_equality_advanced, prove_membership, prove_membership_batch, snark_commit_value,
+    prove_equality, prove_equality_batch, prove_equality_advanced, prove_membership, prove_membership_batch, prove_improvement,
+    prove_improvement_batch, snark_commit_value,
     snark_commit_value_batch, set_snark_key_dir, is_snark_setup_initialized,
     create_proof_batch, batch_add_range_proof, batch_add_equality_proof,
     batch_add_threshold_proof, batch_add_membership_proof, batch_add_improvement_proof, batch_add_consistency_proof,
@@ -17,7 +18,8 @@ from ._native import NativeError  # noqa: F401
 
 __all__ = [
     "prove_range", "prove_range_batch", "prove_threshold", "prove_threshold_batch", "prove_consistency", "prove_consistency_batch",
-    "prove_equality", "prove_equality_batch", "prove_equality_advanced", "prove_membership", "prove_membership_batch", "snark_commit_value",
+    "prove_equality", "prove_equality_batch", "prove_equality_advanced", "prove_membership", "prove_membership_batch", "prove_improvement",
+    "prove_improvement_batch", "snark_commit_value",
     "snark_commit_value_batch", "set_snark_key_dir", "is_snark_setup_initialized",
     "create_proof_batch", "batch_add_range_proof", "batch_add_equality_proof",
     "batch_add_threshold_proof", "batch_add_membership_proof", "batch_add_improvement_proof", "batch_add_consistency_proof",

@@ -299,6 +299,32 @@ def prove_membership_batch(values, sets, seeds=None):
     return [out[i, : lens[i]].tobytes() for i in range(n)]
 
 
+def prove_improvement_batch(olds, news):
+    """Batched prove_improvement (improvement_proof.rs:10-35): Winterfell-style STARK envelopes (scheme 5); deterministic."""
+    n = len(olds)
+    o = np.array([_check_u64("old", x) for x in olds], dtype=np.uint64)
+    w = np.array([_check_u64("new", x) for x in news], dtype=np.uint64)
+    if len(w) != n:
+        raise ValueError("olds, news must have equal length")
+    if (w <= o).any():
+        raise ValueError("new value must be greater than old value")        # validation.rs:63-71
+    if n == 0:
+        return []
+    L = _native.lib()
+    stride = int(L.zkp_hip_improvement_max_bytes())
+    out = np.zeros((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint32)
+    st = np.zeros(n, dtype=np.int32)
+    rc = L.zkp_hip_prove_improvement_batch(n, _P(o), _P(w), _P(out), stride, _P(lens), _P(st))
+    if rc != 0:
+        raise ZkpBackendError("Proof generation failed: STARK proof generation failed%s" % (": " + _native.last_error() if rc < 0 else ""))
+    return [out[i, : lens[i]].tobytes() for i in range(n)]
+
+
+def prove_improvement(old, new):
+    return prove_improvement_batch([old], [new])[0]
+
+
 def prove_equality(val1, val2):
     return prove_equality_batch([val1], [val2])[0]
 
@@ -321,8 +347,6 @@ def prove_range(value, min, max):  # noqa: A002  (reference argument names)
 # ---------------------------------------------------------------- batch registry (batch.rs:18-175)
 _registry = {}
 _registry_lock = threading.Lock()
-_OUT_OF_SCOPE = ("%s proofs are produced by the %s backend, which the HIP path does not cover yet "
-                 "(SURVEY.md section 8 row a11; byte-level parity with Winterfell is unpinnable here)")
 
 
 def create_proof_batch():
@@ -371,6 +395,7 @@ def batch_add_membership_proof(batch_id, value, set):  # noqa: A002
 
 
 def batch_add_improvement_proof(batch_id, old, new):
+    old, new = _check_u64("old", old), _check_u64("new", new)
     if new <= old:
         raise ValueError("new value must be greater than old value")
     _with_batch(batch_id, ("improvement", old, new))
@@ -389,8 +414,6 @@ def process_batch(batch_id, seeds=None):
             raise ValueError("Invalid batch ID: %d" % batch_id)
         ops = _registry.pop(batch_id)
     for op in ops:
-        if op[0] == "improvement":
-            raise NotImplementedError(_OUT_OF_SCOPE % (op[0], "STARK"))
         if op[0] == "membership" and len(op[2]) > MAX_SET_SIZE:      # set_membership.rs:14 (validate_set_size at prove time)
             raise ValueError("set size %d exceeds maximum allowed size %d" % (len(op[2]), MAX_SET_SIZE))
     # bucket by variant (one batched device call each), then restore insertion order (batch.rs:123-131 is order-preserving)
@@ -398,7 +421,7 @@ def process_batch(batch_id, seeds=None):
     if seeds is not None and len(seeds) != 32 * len(ops):
         raise ValueError("seeds must hold 32 bytes per op")
     out = [None] * len(ops)
-    for kind in ("range", "threshold", "consistency", "equality", "membership"):
+    for kind in ("range", "threshold", "consistency", "equality", "membership", "improvement"):
         idx = [i for i, o in enumerate(ops) if o[0] == kind]
         if not idx:
             continue
@@ -412,8 +435,10 @@ def process_batch(batch_id, seeds=None):
             proofs = prove_consistency_batch([o[1] for o in sel], seeds=sd)
         elif kind == "equality":
             proofs = prove_equality_batch([o[1] for o in sel], [o[2] for o in sel], seeds=sd)
-        else:
+        elif kind == "membership":
             proofs = prove_membership_batch([o[1] for o in sel], [list(o[2]) for o in sel], seeds=sd)
+        else:
+            proofs = prove_improvement_batch([o[1] for o in sel], [o[2] for o in sel])
         for i, p in zip(idx, proofs):
             out[i] = p
     return out
@@ -442,10 +467,9 @@ def benchmark_proof_generation_numeric(proof_type, iterations):
                "threshold": lambda: prove_threshold([10, 20, 30, 40], 50),
                "consistency": lambda: prove_consistency([10, 20, 30, 40, 50]),
                "equality": lambda: prove_equality(42, 42),
-               "membership": lambda: prove_membership(25, [10, 20, 25, 30, 40])}
+               "membership": lambda: prove_membership(25, [10, 20, 25, 30, 40]),
+               "improvement": lambda: prove_improvement(30, 50)}                     # mod.rs:100
     if proof_type not in runners:
-        if proof_type == "improvement":
-            raise NotImplementedError(_OUT_OF_SCOPE % (proof_type, "STARK"))
         raise ValueError("unsupported proof type: %s" % proof_type)
     times = []
     for _ in range(iterations):

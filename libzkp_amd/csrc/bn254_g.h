@@ -118,6 +118,45 @@ ZKP_HD inline Jac<fq> g1_madd_lazy(const Jac<fq>& p, const Aff<fq>& q) {
     return r;
 }
 
+// The G2 MSM inner loop: the same formulas over Fq2 with the Karatsuba products kept apart (t0 = a0 b0, t1 = a1 b1,
+// t2 = (a0+a1)(b0+b1); c0 = t0 - t1, c1 = t2 - t0 - t1), so that every sum of products is formed limb-wise from carried
+// product outputs and reduced once: 10 weak reductions per mixed addition instead of ~50 with the always-reduced forms.
+struct fq2k { fq t0, t1, t2; };
+struct fq2s { fq c0, m; };                             // a^2 = (c0, 2 m)
+ZKP_HD inline fq2k fq2_kara(const fq2& a, const fq2& b) { return fq2k{fq_mul(a.c0, b.c0), fq_mul(a.c1, b.c1), fq_mul(fq_add_l(a.c0, a.c1), fq_add_l(b.c0, b.c1))}; }
+ZKP_HD inline fq2 fq2_join(const fq2k& k) { return fq2{fq_sub_k4(k.t0, k.t1), fq_sub_k8(k.t2, fq_add_l(k.t0, k.t1))}; }   // unreduced, uncarried
+ZKP_HD inline fq2s fq2_sq_l(const fq2& a) { return fq2s{fq_mul(fq_add_l(a.c0, a.c1), fq_sub_k4(a.c0, a.c1)), fq_mul(a.c0, a.c1)}; }   // a safe
+ZKP_HD inline Jac<fq2> g2_madd_lazy(const Jac<fq2>& p, const Aff<fq2>& q, bool negate) {
+    const fq zero = fq_zero();
+    const fq2 y2{fq_select(negate, fq_sub_k4(zero, q.y.c0), q.y.c0), fq_select(negate, fq_sub_k4(zero, q.y.c1), q.y.c1)};
+    const fq2s zz = fq2_sq_l(p.Z);
+    const fq2 Z1Z1{zz.c0, fq_dbl_l(zz.m)};
+    const fq2 U2 = fq2_join(fq2_kara(q.x, Z1Z1));
+    const fq2 S2 = fq2_join(fq2_kara(fq2_join(fq2_kara(y2, p.Z)), Z1Z1));
+    const fq2 H{fq_reduce_weak(fq_sub_k4(U2.c0, p.X.c0)), fq_reduce_weak(fq_sub_k4(U2.c1, p.X.c1))};
+    const fq2 sv{fq_reduce_weak(fq_sub_k4(S2.c0, p.Y.c0)), fq_reduce_weak(fq_sub_k4(S2.c1, p.Y.c1))};
+    const fq2s hh = fq2_sq_l(H);
+    const fq2 I{fq_dbl_l(fq_dbl_l(hh.c0)), fq_dbl_l(fq_dbl_l(fq_dbl_l(hh.m)))};                  // 4 HH
+    const fq2k J = fq2_kara(H, I), V = fq2_kara(p.X, I);
+    const fq2s ss = fq2_sq_l(sv);
+    Jac<fq2> r;
+    // X3 = 4 s^2 - J - 2V
+    r.X.c0 = fq_reduce_weak(fq_sub_k16(fq_add_l(fq_dbl_l(fq_dbl_l(ss.c0)), fq_add_l(J.t1, fq_dbl_l(V.t1))), fq_add_l(J.t0, fq_dbl_l(V.t0))));
+    r.X.c1 = fq_reduce_weak(fq_sub_k16(fq_add_l(fq_dbl_l(fq_dbl_l(fq_dbl_l(ss.m))), fq_add_l(fq_add_l(J.t0, J.t1), fq_dbl_l(fq_add_l(V.t0, V.t1)))),
+                                       fq_add_l(J.t2, fq_dbl_l(V.t2))));
+    // Y3 = 2 (s (V - X3) - Y1 J)
+    const fq2 W{fq_sub_k8(V.t0, fq_add_l(V.t1, r.X.c0)), fq_sub_k16(V.t2, fq_add_l(fq_add_l(V.t0, V.t1), r.X.c1))};
+    const fq2k P1 = fq2_kara(sv, W), P2 = fq2_kara(p.Y, fq2_join(J));
+    r.Y.c0 = fq_reduce_weak(fq_dbl_l(fq_sub_k8(fq_add_l(P1.t0, P2.t1), fq_add_l(P1.t1, P2.t0))));
+    r.Y.c1 = fq_reduce_weak(fq_dbl_l(fq_sub_k16(fq_add_l(P1.t2, fq_add_l(P2.t0, P2.t1)), fq_add_l(fq_add_l(P1.t0, P1.t1), P2.t2))));
+    // Z3 = (Z1 + H)^2 - Z1Z1 - HH
+    const fq2 zh{fq_add_l(p.Z.c0, H.c0), fq_add_l(p.Z.c1, H.c1)};
+    const fq zq0 = fq_mul(fq_add_l(zh.c0, zh.c1), fq_sub_k8(zh.c0, zh.c1)), zqm = fq_mul(zh.c0, zh.c1);
+    r.Z.c0 = fq_reduce_weak(fq_sub_k8(zq0, fq_add_l(zz.c0, hh.c0)));
+    r.Z.c1 = fq_reduce_weak(fq_dbl_l(fq_sub_k8(zqm, fq_add_l(zz.m, hh.m))));
+    return r;
+}
+
 // add-2007-bl (Jacobian + Jacobian): 11M + 5S
 template <class F> ZKP_HD inline Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
     if (jac_is_inf(p)) return q;

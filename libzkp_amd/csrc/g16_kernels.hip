@@ -3,7 +3,7 @@
 #include "msm_kernel.h"
 
 struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b1/h/l queries)
-    static constexpr uint32_t AFF_W = 20, ACC_W = G1_JAC_W, MIN_WAVES = 3;
+    static constexpr uint32_t AFF_W = 20, ACC_W = G1_JAC_W, MIN_WAVES = 4;
     using Acc = g1_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq>(); }
     static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
@@ -23,8 +23,7 @@ struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
     static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
         const uint32_t* e = subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W;
         g2_aff q; ZKP_UNROLL for (int k = 0; k < 10; k++) { q.x.c0.v[k] = e[k]; q.x.c1.v[k] = e[10 + k]; q.y.c0.v[k] = e[20 + k]; q.y.c1.v[k] = e[30 + k]; }
-        q.y = f_select(d < 0, f_neg(q.y), q.y);
-        return jac_madd_nocheck(acc, q);
+        return g2_madd_lazy(acc, q, d < 0);
     }
     static __device__ __forceinline__ void store(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const Acc& a) { st_g2_jac(p, idx, row, rows, a); }
     static __device__ __forceinline__ Acc load(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) { return ld_g2_jac(p, idx, row, rows); }

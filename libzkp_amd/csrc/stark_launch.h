@@ -1,0 +1,8 @@
+// Host-callable launcher of the improvement-proof (STARK) kernel, defined in stark_kernels.hip (third translation unit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "stark_steps.h"
+
+// one wavefront per proof; ops with new <= old produce out_len = 0 (the host front end reports them as InvalidInput)
+void stark_launch_prove(const uint64_t* d_old, const uint64_t* d_new, uint32_t n, const zkp::StarkConst* d_const, uint8_t* d_out, uint64_t stride,
+                        uint32_t* d_out_len, hipStream_t st);

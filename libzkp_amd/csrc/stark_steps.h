@@ -1,0 +1,435 @@
+// libzkp's improvement proof (Winterfell STARK, 8-row x 1-column trace over p = 2^128 - 45*2^40 + 1) as cooperative
+// per-proof steps: `nthreads` lanes (64 on the GPU = one wavefront per proof, 1 in host emulation) share a ProofMem
+// block (LDS on the GPU); `sync` is the barrier between steps.  Lane i owns row i of the 64-point LDE domain: it
+// evaluates the trace / composition column there, hashes the row (BLAKE3) and takes part in the Merkle levels; the
+// Fiat-Shamir coin, the out-of-domain frame, the DEEP/FRI remainder and the serialisation run on lane 0 (they are a
+// strictly serial hash chain of ~25 compressions).
+// Replaces winterfell's Prover::prove as called by StarkBackend::prove_improvement (/root/reference/src/backend/stark.rs:151-186)
+// and the envelope framing of proof/improvement_proof.rs:10-35 + utils/commitment.rs:38-50.  Pipeline and byte layout:
+// see oracle/py/stark.py (the restatement this code is tested against, bit for bit).
+#pragma once
+#include "zkp_common.h"
+// The hash compression, the field product and the serial tail are real (non-inlined) device functions: the kernel is
+// latency-bound on lane 0's hash chain, not on call overhead, and full inlining made a 60k-instruction kernel that took
+// 12 minutes to compile.
+
+namespace zkp {
+
+// ---------------------------------------------------------------------------------------------- field
+struct f128 { uint64_t lo, hi; };
+#define ZKP_F128_C 0x2CFFFFFFFFFFull            /* 2^128 mod p = 45 * 2^40 - 1 */
+#define ZKP_F128_PLO 0xFFFFD30000000001ull      /* p = 2^128 - 45 * 2^40 + 1 */
+#define ZKP_F128_PHI 0xFFFFFFFFFFFFFFFFull
+
+ZKP_HD inline void mul64wide(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    lo = a * b; hi = __umul64hi(a, b);
+#else
+    const unsigned __int128 p = (unsigned __int128)a * b; lo = (uint64_t)p; hi = (uint64_t)(p >> 64);
+#endif
+}
+ZKP_HD inline f128 f128_make(uint64_t lo, uint64_t hi = 0) { f128 r; r.lo = lo; r.hi = hi; return r; }
+ZKP_HD inline bool f128_geq_p(const f128& a) { return a.hi == ZKP_F128_PHI && a.lo >= ZKP_F128_PLO; }
+ZKP_HD inline f128 f128_canon(const f128& a) { return f128_geq_p(a) ? f128_make(a.lo - ZKP_F128_PLO, 0) : a; }
+// all routines take and return canonical values (< p)
+ZKP_HD inline f128 f128_add(const f128& a, const f128& b) {
+    f128 r; r.lo = a.lo + b.lo; const uint64_t c0 = r.lo < a.lo;
+    r.hi = a.hi + b.hi; const uint64_t c1 = r.hi < a.hi; r.hi += c0; const uint64_t c2 = r.hi < c0;
+    if (c1 | c2) {                                  // wrapped 2^128: add 2^128 mod p (cannot wrap again: the sum is < 2p)
+        const uint64_t t = r.lo + ZKP_F128_C; r.hi += t < r.lo; r.lo = t;
+    }
+    return f128_canon(r);
+}
+ZKP_HD inline f128 f128_neg(const f128& a) {
+    if ((a.lo | a.hi) == 0) return a;
+    f128 r; r.lo = ZKP_F128_PLO - a.lo; r.hi = ZKP_F128_PHI - a.hi - (ZKP_F128_PLO < a.lo); return r;
+}
+ZKP_HD inline f128 f128_sub(const f128& a, const f128& b) { return f128_add(a, f128_neg(b)); }
+ZKP_HD_NOINLINE inline f128 f128_mul(const f128& a, const f128& b) {
+    // 256-bit product w3..w0
+    uint64_t w0, w1, w2, w3, h, l;
+    mul64wide(a.lo, b.lo, w1, w0);
+    mul64wide(a.hi, b.hi, w3, w2);
+    mul64wide(a.lo, b.hi, h, l);
+    w1 += l; uint64_t c = w1 < l; w2 += c; c = w2 < c; w3 += c;
+    w2 += h; w3 += w2 < h;
+    mul64wide(a.hi, b.lo, h, l);
+    w1 += l; c = w1 < l; w2 += c; c = w2 < c; w3 += c;
+    w2 += h; w3 += w2 < h;
+    // (w3 w2) * C : 128 x 46 bits -> 174 bits (t2 t1 t0), t2 < 2^46
+    uint64_t t0, t1, t2, x;
+    mul64wide(w2, ZKP_F128_C, t1, t0);
+    mul64wide(w3, ZKP_F128_C, t2, x);
+    t1 += x; t2 += t1 < x;
+    // t2 * C < 2^92
+    uint64_t u0, u1;
+    mul64wide(t2, ZKP_F128_C, u1, u0);
+    // r = (w1 w0) + (t1 t0) + (u1 u0), counting the wraps past 2^128 (at most 2)
+    f128 r; uint64_t wraps = 0;
+    r.lo = w0 + t0; c = r.lo < w0;
+    r.hi = w1 + t1; wraps += r.hi < w1; r.hi += c; wraps += r.hi < c;
+    x = r.lo + u0; c = x < r.lo; r.lo = x;
+    x = r.hi + u1; wraps += x < r.hi; r.hi = x; r.hi += c; wraps += r.hi < c;
+    while (wraps) {                                  // each wrap past 2^128 is worth C; adding it may (rarely) wrap once more
+        wraps--;
+        x = r.lo + ZKP_F128_C; c = x < r.lo; r.lo = x;
+        x = r.hi + c; if (x < r.hi) wraps++; r.hi = x;
+    }
+    return f128_canon(r);
+}
+ZKP_HD inline f128 f128_pow(const f128& a, uint64_t e_lo, uint64_t e_hi) {
+    f128 acc = f128_make(1);
+    for (int i = 127; i >= 0; i--) {
+        acc = f128_mul(acc, acc);
+        const uint64_t bit = i >= 64 ? (e_hi >> (i - 64)) & 1 : (e_lo >> i) & 1;
+        if (bit) acc = f128_mul(acc, a);
+    }
+    return acc;
+}
+ZKP_HD inline f128 f128_inv(const f128& a) { return f128_pow(a, ZKP_F128_PLO - 2, ZKP_F128_PHI); }   // host-side table construction only
+
+// ---------------------------------------------------------------------------------------------- BLAKE3 (inputs <= 1 chunk, whole words)
+ZKP_HD constexpr uint32_t blake3_iv(int i) { constexpr uint32_t iv[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u}; return iv[i]; }
+ZKP_HD inline uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+#define ZKP_B3_G(a, b, c, d, mx, my)                                                                      \
+    do {                                                                                                  \
+        s[a] = s[a] + s[b] + (mx); s[d] = rotr32(s[d] ^ s[a], 16); s[c] = s[c] + s[d]; s[b] = rotr32(s[b] ^ s[c], 12); \
+        s[a] = s[a] + s[b] + (my); s[d] = rotr32(s[d] ^ s[a], 8); s[c] = s[c] + s[d]; s[b] = rotr32(s[b] ^ s[c], 7);   \
+    } while (0)
+// chaining value update for one block (counter 0)
+ZKP_HD_NOINLINE inline void blake3_compress(uint32_t cv[8], const uint32_t block[16], uint32_t block_len, uint32_t flags) {
+    uint32_t s[16], m[16];
+    ZKP_UNROLL for (int i = 0; i < 8; i++) s[i] = cv[i];
+    ZKP_UNROLL for (int i = 0; i < 4; i++) s[8 + i] = blake3_iv(i);
+    s[12] = 0; s[13] = 0; s[14] = block_len; s[15] = flags;
+    ZKP_UNROLL for (int i = 0; i < 16; i++) m[i] = block[i];
+    ZKP_UNROLL for (int r = 0; r < 7; r++) {
+        ZKP_B3_G(0, 4, 8, 12, m[0], m[1]); ZKP_B3_G(1, 5, 9, 13, m[2], m[3]); ZKP_B3_G(2, 6, 10, 14, m[4], m[5]); ZKP_B3_G(3, 7, 11, 15, m[6], m[7]);
+        ZKP_B3_G(0, 5, 10, 15, m[8], m[9]); ZKP_B3_G(1, 6, 11, 12, m[10], m[11]); ZKP_B3_G(2, 7, 8, 13, m[12], m[13]); ZKP_B3_G(3, 4, 9, 14, m[14], m[15]);
+        if (r < 6) {
+            const uint32_t t[16] = {m[2], m[6], m[3], m[10], m[7], m[0], m[4], m[13], m[1], m[11], m[12], m[5], m[9], m[14], m[15], m[8]};
+            ZKP_UNROLL for (int i = 0; i < 16; i++) m[i] = t[i];
+        }
+    }
+    ZKP_UNROLL for (int i = 0; i < 8; i++) cv[i] = s[i] ^ s[i + 8];
+}
+// BLAKE3 of nwords 32-bit little-endian words (nwords <= 256)
+ZKP_HD_NOINLINE inline void blake3_words(uint32_t out[8], const uint32_t* in, uint32_t nwords) {
+    ZKP_UNROLL for (int i = 0; i < 8; i++) out[i] = blake3_iv(i);
+    const uint32_t nblocks = nwords == 0 ? 1 : (nwords + 15) / 16;
+    for (uint32_t b = 0; b < nblocks; b++) {
+        uint32_t m[16];
+        const uint32_t have = nwords - 16 * b < 16 ? nwords - 16 * b : 16;
+        ZKP_UNROLL for (uint32_t i = 0; i < 16; i++) m[i] = i < have ? in[16 * b + i] : 0u;
+        blake3_compress(out, m, 4 * have, (b == 0 ? 1u : 0u) | (b == nblocks - 1 ? 10u : 0u));   // CHUNK_START | CHUNK_END + ROOT
+    }
+}
+ZKP_HD inline void blake3_merge(uint32_t out[8], const uint32_t a[8], const uint32_t b[8]) {
+    uint32_t m[16]; ZKP_UNROLL for (int i = 0; i < 8; i++) { m[i] = a[i]; m[8 + i] = b[i]; }
+    ZKP_UNROLL for (int i = 0; i < 8; i++) out[i] = blake3_iv(i);
+    blake3_compress(out, m, 64, 11);
+}
+ZKP_HD inline void blake3_merge_int(uint32_t out[8], const uint32_t seed[8], uint64_t v) {
+    uint32_t m[16]; ZKP_UNROLL for (int i = 0; i < 8; i++) { m[i] = seed[i]; m[8 + i] = 0; }
+    m[8] = (uint32_t)v; m[9] = (uint32_t)(v >> 32);
+    ZKP_UNROLL for (int i = 0; i < 8; i++) out[i] = blake3_iv(i);
+    blake3_compress(out, m, 40, 11);
+}
+ZKP_HD inline void f128_words(uint32_t w[4], const f128& a) { w[0] = (uint32_t)a.lo; w[1] = (uint32_t)(a.lo >> 32); w[2] = (uint32_t)a.hi; w[3] = (uint32_t)(a.hi >> 32); }
+ZKP_HD inline void blake3_elements(uint32_t out[8], const f128* e, uint32_t n) {   // n <= 16
+    uint32_t w[64];
+    for (uint32_t i = 0; i < n; i++) f128_words(w + 4 * i, e[i]);
+    blake3_words(out, w, 4 * n);
+}
+
+// ---------------------------------------------------------------------------------------------- SHA-256 of the 37-byte binding commitment
+ZKP_HD constexpr uint32_t sha256_k(int i) {
+    constexpr uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+        0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+        0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+        0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+        0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+        0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    return K[i];
+}
+// SHA-256("libzkp_improvement_v1" || u64le(old) || u64le(new))  (utils/commitment.rs:38-50); one padded block
+ZKP_HD_NOINLINE inline void improvement_commitment(uint8_t out[32], uint64_t oldv, uint64_t newv) {
+    uint8_t blk[64];
+    const char tag[22] = "libzkp_improvement_v1";
+    for (int i = 0; i < 21; i++) blk[i] = (uint8_t)tag[i];
+    for (int i = 0; i < 8; i++) { blk[21 + i] = (uint8_t)(oldv >> (8 * i)); blk[29 + i] = (uint8_t)(newv >> (8 * i)); }
+    blk[37] = 0x80; for (int i = 38; i < 64; i++) blk[i] = 0;
+    blk[62] = (uint8_t)((37 * 8) >> 8); blk[63] = (uint8_t)(37 * 8);
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = ((uint32_t)blk[4 * i] << 24) | ((uint32_t)blk[4 * i + 1] << 16) | ((uint32_t)blk[4 * i + 2] << 8) | blk[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+        const uint32_t s0 = rotr32(w[i - 15], 7) ^ rotr32(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr32(w[i - 2], 17) ^ rotr32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+        const uint32_t t1 = hh + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + sha256_k(i) + w[i];
+        const uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    for (int k = 0; k < 8; k++) { out[4 * k] = (uint8_t)(h[k] >> 24); out[4 * k + 1] = (uint8_t)(h[k] >> 16); out[4 * k + 2] = (uint8_t)(h[k] >> 8); out[4 * k + 3] = (uint8_t)h[k]; }
+}
+
+// ---------------------------------------------------------------------------------------------- the prover
+constexpr uint32_t STARK_TRACE_LEN = 8, STARK_LDE = 64, STARK_CE = 16, STARK_QUERIES = 32, STARK_DEPTH = 6;
+constexpr uint32_t STARK_MAX_PROOF = 3469;                    // 32 distinct positions, 32 sibling nodes per opening
+constexpr uint32_t STARK_MAX_ENVELOPE = 10 + 16 + STARK_MAX_PROOF + 32;
+
+// domain constants, built once on the host (stark_build_constants) and kept in device memory
+struct StarkConst {
+    f128 x_lde[STARK_LDE];              // 3 * w64^i
+    f128 w8_inv_pow[8], w16_inv_pow[16];
+    f128 scale8;                        // 1/8
+    f128 scale16[8];                    // 3^-k / 16
+    f128 inv_zt[STARK_CE], inv_xm1[STARK_CE], inv_xml[STARK_CE];   // 1 / Z_t(x), 1/(x - 1), 1/(x - g^7) on the 16-point coset
+    f128 inv7, g, g_last;               // 1/7, w8, w8^7
+    uint32_t seed_prefix[32];           // the eight context elements of the coin seed, as words
+    uint8_t context_bytes[28];
+};
+inline void stark_build_constants(StarkConst& C) {
+    const f128 gen = f128_make(3);
+    // two-adic root: 3^((p-1)/2^40); (p-1)/2^40 = 2^88 - 45
+    const f128 tw = f128_pow(gen, (uint64_t)0 - 45ull, (1ull << 24) - 1);   // 2^88 - 45 = (2^24 - 1) * 2^64 + (2^64 - 45)
+    auto root = [&](uint32_t log_n) { f128 r = tw; for (uint32_t i = log_n; i < 40; i++) r = f128_mul(r, r); return r; };
+    const f128 w64 = root(6), w16 = root(4), w8 = root(3);
+    f128 x = gen;
+    for (uint32_t i = 0; i < STARK_LDE; i++) { C.x_lde[i] = x; x = f128_mul(x, w64); }
+    const f128 w8i = f128_inv(w8), w16i = f128_inv(w16);
+    C.w8_inv_pow[0] = f128_make(1); for (int i = 1; i < 8; i++) C.w8_inv_pow[i] = f128_mul(C.w8_inv_pow[i - 1], w8i);
+    C.w16_inv_pow[0] = f128_make(1); for (int i = 1; i < 16; i++) C.w16_inv_pow[i] = f128_mul(C.w16_inv_pow[i - 1], w16i);
+    C.scale8 = f128_inv(f128_make(8));
+    const f128 gi = f128_inv(gen); f128 s = f128_inv(f128_make(16));
+    for (int k = 0; k < 8; k++) { C.scale16[k] = s; s = f128_mul(s, gi); }
+    C.inv7 = f128_inv(f128_make(7)); C.g = w8;
+    f128 last = f128_make(1); for (int i = 0; i < 7; i++) last = f128_mul(last, w8);
+    C.g_last = last;
+    for (uint32_t i = 0; i < STARK_CE; i++) {
+        const f128 xc = C.x_lde[i * (STARK_LDE / STARK_CE)];
+        f128 x8 = xc; for (int k = 0; k < 3; k++) x8 = f128_mul(x8, x8);
+        const f128 zt = f128_mul(f128_sub(x8, f128_make(1)), f128_inv(f128_sub(xc, last)));
+        C.inv_zt[i] = f128_inv(zt); C.inv_xm1[i] = f128_inv(f128_sub(xc, f128_make(1))); C.inv_xml[i] = f128_inv(f128_sub(xc, last));
+    }
+    const f128 ctx[8] = {f128_make(256), f128_make(8), f128_make(ZKP_F128_PLO), f128_make(ZKP_F128_PHI), f128_make((1u << 16) | (8u << 8) | 31u), f128_make(0), f128_make(8), f128_make(32)};
+    for (int i = 0; i < 8; i++) f128_words(C.seed_prefix + 4 * i, ctx[i]);
+    const uint8_t head[6] = {1, 0, 3, 0, 0, 16};
+    for (int i = 0; i < 6; i++) C.context_bytes[i] = head[i];
+    for (int i = 0; i < 8; i++) { C.context_bytes[6 + i] = (uint8_t)(ZKP_F128_PLO >> (8 * i)); C.context_bytes[14 + i] = 0xFF; }
+    const uint8_t opt[6] = {32, 8, 0, 1, 8, 31};
+    for (int i = 0; i < 6; i++) C.context_bytes[22 + i] = opt[i];
+}
+
+// per-proof shared block (LDS on the GPU)
+struct StarkMem {
+    f128 t_poly[8], h_poly[8], t_lde[STARK_LDE], h_lde[STARK_LDE], ce[STARK_CE], col[8];
+    uint32_t t_leaf[STARK_LDE][8], h_leaf[STARK_LDE][8], t_node[STARK_LDE][8], h_node[STARK_LDE][8];   // node i: children 2i, 2i+1; [1] = root
+    uint32_t seed[8]; uint64_t counter;
+    f128 coef[3], step, oldv, newv;
+    uint32_t out_len;
+    uint8_t out[STARK_MAX_ENVELOPE + 3];
+};
+
+ZKP_HD_NOINLINE inline f128 stark_horner8(const f128* c, const f128& x) {
+    f128 acc = c[7];
+    for (int i = 6; i >= 0; i--) acc = f128_add(f128_mul(acc, x), c[i]);
+    return acc;
+}
+// ---- coin (lane 0)
+ZKP_HD inline void coin_reseed(StarkMem& M, const uint32_t d[8]) { uint32_t s[8]; blake3_merge(s, M.seed, d); for (int i = 0; i < 8; i++) M.seed[i] = s[i]; M.counter = 0; }
+ZKP_HD inline void coin_next(StarkMem& M, uint32_t out[8]) { M.counter++; blake3_merge_int(out, M.seed, M.counter); }
+ZKP_HD inline f128 coin_draw(StarkMem& M) {
+    for (int tries = 0; tries < 1000; tries++) {
+        uint32_t d[8]; coin_next(M, d);
+        f128 v; v.lo = (uint64_t)d[0] | ((uint64_t)d[1] << 32); v.hi = (uint64_t)d[2] | ((uint64_t)d[3] << 32);
+        if (!f128_geq_p(v)) return v;
+    }
+    return f128_make(0);
+}
+
+// ---- step 0 (lanes 0..7 useful): trace column, its interpolation; lane 0: coin seed
+ZKP_HD inline void stark_step_trace(StarkMem& M, const StarkConst& C, uint64_t oldv, uint64_t newv, uint32_t tid, uint32_t nthreads) {
+    const f128 o = f128_make(oldv), n = f128_make(newv);
+    const f128 step = f128_mul(f128_sub(n, o), C.inv7);
+    for (uint32_t i = tid; i < 8; i += nthreads) {
+        f128 v = o; for (uint32_t k = 0; k < i; k++) v = f128_add(v, step);
+        M.col[i] = v;
+    }
+    if (tid == 0) {
+        M.step = step; M.oldv = o; M.newv = n;
+        uint32_t w[40];
+        for (int i = 0; i < 32; i++) w[i] = C.seed_prefix[i];
+        f128_words(w + 32, o); f128_words(w + 36, n);
+        blake3_words(M.seed, w, 40); M.counter = 0;
+    }
+}
+ZKP_HD inline void stark_step_interp_trace(StarkMem& M, const StarkConst& C, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t k = tid; k < 8; k += nthreads) {
+        f128 acc = f128_make(0);
+        for (uint32_t i = 0; i < 8; i++) acc = f128_add(acc, f128_mul(M.col[i], C.w8_inv_pow[(i * k) & 7]));
+        M.t_poly[k] = f128_mul(acc, C.scale8);
+    }
+}
+// ---- LDE of one column + row hashes (lane = row)
+ZKP_HD inline void stark_step_lde(const f128* poly, f128* lde, uint32_t (*leaf)[8], const StarkConst& C, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid; i < STARK_LDE; i += nthreads) {
+        const f128 v = stark_horner8(poly, C.x_lde[i]);
+        lde[i] = v;
+        uint32_t w[4]; f128_words(w, v);
+        blake3_words(leaf[i], w, 4);
+    }
+}
+// one Merkle level: nodes [width, 2*width) from the level below (leaves when width == 32)
+ZKP_HD inline void stark_step_merkle_level(uint32_t (*leaf)[8], uint32_t (*node)[8], uint32_t width, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t j = tid; j < width; j += nthreads) {
+        const uint32_t i = width + j;
+        if (width == STARK_LDE / 2) blake3_merge(node[i], leaf[2 * j], leaf[2 * j + 1]);
+        else blake3_merge(node[i], node[2 * i], node[2 * i + 1]);
+    }
+}
+// ---- lane 0: reseed with the trace root, draw the constraint composition coefficients
+ZKP_HD inline void stark_step_coefficients(StarkMem& M, uint32_t tid) {
+    if (tid != 0) return;
+    coin_reseed(M, M.t_node[1]);
+    for (int i = 0; i < 3; i++) M.coef[i] = coin_draw(M);
+}
+// ---- lanes 0..15: combined constraint evaluations on the constraint-evaluation coset
+ZKP_HD inline void stark_step_constraints(StarkMem& M, const StarkConst& C, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid; i < STARK_CE; i += nthreads) {
+        const uint32_t row = i * (STARK_LDE / STARK_CE);
+        const f128 cur = M.t_lde[row], nxt = M.t_lde[(row + 8) & (STARK_LDE - 1)];
+        const f128 t = f128_mul(f128_mul(M.coef[0], f128_sub(f128_sub(nxt, cur), M.step)), C.inv_zt[i]);
+        const f128 b0 = f128_mul(f128_mul(M.coef[1], f128_sub(cur, M.oldv)), C.inv_xm1[i]);
+        const f128 b1 = f128_mul(f128_mul(M.coef[2], f128_sub(cur, M.newv)), C.inv_xml[i]);
+        M.ce[i] = f128_add(f128_add(t, b0), b1);
+    }
+}
+// ---- lanes 0..7: interpolate the 16 evaluations on the coset; the composition column is the low 8 coefficients
+ZKP_HD inline void stark_step_interp_constraints(StarkMem& M, const StarkConst& C, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t k = tid; k < 8; k += nthreads) {
+        f128 acc = f128_make(0);
+        for (uint32_t i = 0; i < STARK_CE; i++) acc = f128_add(acc, f128_mul(M.ce[i], C.w16_inv_pow[(i * k) & 15]));
+        M.h_poly[k] = f128_mul(acc, C.scale16[k]);
+    }
+}
+
+// ---- serialisation helpers (lane 0)
+struct StarkWriter {
+    uint8_t* p; uint32_t n;
+    ZKP_HD void u8(uint32_t v) { p[n++] = (uint8_t)v; }
+    ZKP_HD void u16(uint32_t v) { u8(v); u8(v >> 8); }
+    ZKP_HD void u64(uint64_t v) { for (int i = 0; i < 8; i++) u8((uint32_t)(v >> (8 * i))); }
+    ZKP_HD void vint(uint32_t v) { if (v < 128) u8((v << 1) | 1); else if (v < 16384) { const uint32_t e = ((v << 1) | 1) << 1; u8(e); u8(e >> 8); } else { const uint32_t e = ((v << 1) | 1) << 2; u8(e); u8(e >> 8); u8(e >> 16); } }
+    ZKP_HD void words(const uint32_t* w, uint32_t k) { for (uint32_t i = 0; i < k; i++) { u8(w[i]); u8(w[i] >> 8); u8(w[i] >> 16); u8(w[i] >> 24); } }
+    ZKP_HD void el(const f128& a) { uint32_t w[4]; f128_words(w, a); words(w, 4); }
+};
+// queried values + batch Merkle opening of one commitment (positions = set bits of `mask`, ascending)
+ZKP_HD_NOINLINE inline void stark_write_queries(StarkWriter& W, const f128* lde, uint32_t (*leaf)[8], uint32_t (*node)[8], uint64_t mask, uint32_t count) {
+    W.vint(16 * count);
+    for (uint32_t i = 0; i < STARK_LDE; i++) if ((mask >> i) & 1) W.el(lde[i]);
+    // batch opening: one node list per queried sibling pair
+    uint8_t idx[32], nxt[32]; uint8_t cnt[32]; uint8_t store[32][6];   // per list: up to 1 leaf + 5 internal siblings, as (level, index) codes
+    uint32_t npairs = 0;
+    for (uint32_t pr = 0; pr < STARK_LDE; pr += 2) {
+        const uint32_t a = (uint32_t)(mask >> pr) & 1, b = (uint32_t)(mask >> (pr + 1)) & 1;
+        if (!(a | b)) continue;
+        cnt[npairs] = 0;
+        if (!a) store[npairs][cnt[npairs]++] = (uint8_t)(0x80 | pr);             // leaf code: 0x80 | leaf index
+        if (!b) store[npairs][cnt[npairs]++] = (uint8_t)(0x80 | (pr + 1));
+        idx[npairs] = (uint8_t)((pr + STARK_LDE) >> 1);
+        npairs++;
+    }
+    uint32_t ncur = npairs;
+    for (uint32_t level = 1; level < STARK_DEPTH; level++) {
+        uint32_t nn = 0, i = 0;
+        while (i < ncur) {
+            const uint32_t sib = idx[i] ^ 1u;
+            if (i + 1 < ncur && idx[i + 1] == sib) i++;
+            else store[i][cnt[i]++] = (uint8_t)sib;                               // internal node code: its index (< 64)
+            nxt[nn++] = (uint8_t)(sib >> 1);
+            i++;
+        }
+        for (uint32_t k = 0; k < nn; k++) idx[k] = nxt[k];
+        ncur = nn;
+    }
+    uint32_t total = 0; for (uint32_t k = 0; k < npairs; k++) total += cnt[k];
+    W.vint(1 + 1 + npairs + 32 * total);                                          // depth byte, list count (npairs <= 32: one byte), list headers, digests
+    W.u8(STARK_DEPTH); W.vint(npairs);
+    for (uint32_t k = 0; k < npairs; k++) {
+        W.u8(cnt[k]);
+        for (uint32_t j = 0; j < cnt[k]; j++) { const uint32_t c = store[k][j]; W.words((c & 0x80) ? leaf[c & 0x7F] : node[c], 8); }
+    }
+}
+// ---- lane 0: everything after the constraint commitment
+ZKP_HD_NOINLINE inline void stark_step_finish(StarkMem& M, const StarkConst& C, uint64_t oldv, uint64_t newv, uint32_t tid) {
+    if (tid != 0) return;
+    coin_reseed(M, M.h_node[1]);
+    const f128 z = coin_draw(M), zg = f128_mul(z, C.g);
+    const f128 tz = stark_horner8(M.t_poly, z), tzg = stark_horner8(M.t_poly, zg);
+    uint32_t d[8];
+    { const f128 e[2] = {tz, tzg}; blake3_elements(d, e, 2); coin_reseed(M, d); }
+    const f128 hz = stark_horner8(M.h_poly, z);
+    blake3_elements(d, &hz, 1); coin_reseed(M, d);
+    const f128 dc0 = coin_draw(M), dc1 = coin_draw(M);
+    // DEEP polynomial: dc0 * ((T - T(z))/(x - z) + (T - T(zg))/(x - zg)) + dc1 * (H - H(z))/(x - z), by synthetic division
+    f128 rem[8];
+    {
+        f128 c1 = f128_make(0), c2 = f128_make(0), c3 = f128_make(0);
+        rem[7] = f128_make(0);
+        for (int i = 7; i >= 1; i--) {
+            c1 = f128_add(M.t_poly[i], f128_mul(c1, z));
+            c2 = f128_add(M.t_poly[i], f128_mul(c2, zg));
+            c3 = f128_add(M.h_poly[i], f128_mul(c3, z));
+            rem[i - 1] = f128_add(f128_mul(dc0, f128_add(c1, c2)), f128_mul(dc1, c3));
+        }
+    }
+    uint32_t rc[8]; blake3_elements(rc, rem, 8);
+    coin_reseed(M, rc);
+    // query positions: nonce 0, 32 draws of 6 bits, sorted + deduplicated = a 64-bit set
+    { uint32_t s[8]; blake3_merge_int(s, M.seed, 0); for (int i = 0; i < 8; i++) M.seed[i] = s[i]; M.counter = 0; }
+    uint64_t mask = 0;
+    for (uint32_t q = 0; q < STARK_QUERIES; q++) { coin_next(M, d); mask |= 1ull << (d[0] & (STARK_LDE - 1)); }
+    uint32_t count = 0; for (uint32_t i = 0; i < STARK_LDE; i++) count += (uint32_t)(mask >> i) & 1;
+    // envelope: [2][5][u32 payload][u32 32][old][new][stark proof][commitment]
+    StarkWriter W{M.out, 0};
+    W.u8(2); W.u8(5); W.n += 4; W.u8(32); W.u8(0); W.u8(0); W.u8(0);
+    W.u64(oldv); W.u64(newv);
+    for (int i = 0; i < 28; i++) W.u8(C.context_bytes[i]);
+    W.u8(count);
+    W.u16(96); W.words(M.t_node[1], 8); W.words(M.h_node[1], 8); W.words(rc, 8);
+    stark_write_queries(W, M.t_lde, M.t_leaf, M.t_node, mask, count);
+    stark_write_queries(W, M.h_lde, M.h_leaf, M.h_node, mask, count);
+    W.u16(33); W.u8(2); W.el(tz); W.el(tzg);
+    W.u16(16); W.el(hz);
+    W.u8(0); W.u16(128); for (int i = 0; i < 8; i++) W.el(rem[i]);
+    W.u8(1);
+    W.u64(0); W.u8(0);
+    const uint32_t payload = W.n - 10;
+    M.out[2] = (uint8_t)payload; M.out[3] = (uint8_t)(payload >> 8); M.out[4] = (uint8_t)(payload >> 16); M.out[5] = (uint8_t)(payload >> 24);
+    uint8_t cm[32]; improvement_commitment(cm, oldv, newv);
+    for (int i = 0; i < 32; i++) W.u8(cm[i]);
+    M.out_len = W.n;
+}
+
+// the whole proof; host emulation runs it with nthreads = 1 and a no-op barrier
+template <class Sync>
+ZKP_HD inline void stark_prove(StarkMem& M, const StarkConst& C, uint64_t oldv, uint64_t newv, uint32_t tid, uint32_t nthreads, Sync sync) {
+    stark_step_trace(M, C, oldv, newv, tid, nthreads); sync();
+    stark_step_interp_trace(M, C, tid, nthreads); sync();
+    stark_step_lde(M.t_poly, M.t_lde, M.t_leaf, C, tid, nthreads); sync();
+    for (uint32_t w = STARK_LDE / 2; w >= 1; w >>= 1) { stark_step_merkle_level(M.t_leaf, M.t_node, w, tid, nthreads); sync(); }
+    stark_step_coefficients(M, tid); sync();
+    stark_step_constraints(M, C, tid, nthreads); sync();
+    stark_step_interp_constraints(M, C, tid, nthreads); sync();
+    stark_step_lde(M.h_poly, M.h_lde, M.h_leaf, C, tid, nthreads); sync();
+    for (uint32_t w = STARK_LDE / 2; w >= 1; w >>= 1) { stark_step_merkle_level(M.h_leaf, M.h_node, w, tid, nthreads); sync(); }
+    stark_step_finish(M, C, oldv, newv, tid); sync();
+}
+
+}  // namespace zkp

@@ -21,6 +21,7 @@
 #include "g16_circuit.h"
 #include "msm_kernel.h"
 #include "g16_launch.h"
+#include "stark_launch.h"
 #include "../../include/libzkp_hip.h"
 
 // ================================================================================================ kernels
@@ -489,6 +490,7 @@ int fresh_seeds(std::vector<uint8_t>& buf, size_t n) {
 }  // namespace
 
 #include "g16_impl.inc"
+#include "stark_impl.inc"
 
 // ================================================================================================ C ABI
 extern "C" {

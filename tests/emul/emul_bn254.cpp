@@ -48,8 +48,7 @@ void emul_g2_lazy_chain(const uint32_t o[32], const uint32_t* pts, const int* si
     g2_jac acc = jac_dbl(jac_from_aff(load_g2(o)));
     for (int i = 0; i < n; i++) {
         g2_aff q = load_g2(pts + 32 * i);
-        q.y = f_select(signs[i] < 0, f_neg(q.y), q.y);
-        acc = jac_madd_nocheck(acc, q);
+        acc = g2_madd_lazy(acc, q, signs[i] < 0);
     }
     g2_serialize(out, acc);
 }

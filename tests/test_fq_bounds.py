@@ -115,6 +115,50 @@ def test_g1_madd_lazy_is_closed_over_safe_inputs():
         assert all(o.val <= 3000 and max(o.l[:9]) <= M26 for o in out)
 
 
+def kara(a, b):
+    return mul(a[0], b[0]), mul(a[1], b[1]), mul(add_l(a[0], a[1]), add_l(b[0], b[1]))
+
+
+def join(k):
+    return sub_k(4, k[0], k[1]), sub_k(8, k[2], add_l(k[0], k[1]))
+
+
+def sq_l(a):
+    return mul(add_l(a[0], a[1]), sub_k(4, a[0], a[1])), mul(a[0], a[1])
+
+
+def g2_madd_lazy(X1, Y1, Z1, x2, y2):
+    zz = sq_l(Z1)
+    Z1Z1 = (zz[0], dbl_l(zz[1]))
+    U2 = join(kara(x2, Z1Z1))
+    S2 = join(kara(join(kara(y2, Z1)), Z1Z1))
+    H = tuple(reduce_weak(sub_k(4, U2[i], X1[i])) for i in range(2))
+    sv = tuple(reduce_weak(sub_k(4, S2[i], Y1[i])) for i in range(2))
+    hh = sq_l(H)
+    I = (dbl_l(dbl_l(hh[0])), dbl_l(dbl_l(dbl_l(hh[1]))))
+    J, Vk = kara(H, I), kara(X1, I)
+    ss = sq_l(sv)
+    X3 = (reduce_weak(sub_k(16, add_l(dbl_l(dbl_l(ss[0])), add_l(J[1], dbl_l(Vk[1]))), add_l(J[0], dbl_l(Vk[0])))),
+          reduce_weak(sub_k(16, add_l(dbl_l(dbl_l(dbl_l(ss[1]))), add_l(add_l(J[0], J[1]), dbl_l(add_l(Vk[0], Vk[1])))), add_l(J[2], dbl_l(Vk[2])))))
+    Wv = (sub_k(8, Vk[0], add_l(Vk[1], X3[0])), sub_k(16, Vk[2], add_l(add_l(Vk[0], Vk[1]), X3[1])))
+    P1, P2 = kara(sv, Wv), kara(Y1, join(J))
+    Y3 = (reduce_weak(dbl_l(sub_k(8, add_l(P1[0], P2[1]), add_l(P1[1], P2[0])))),
+          reduce_weak(dbl_l(sub_k(16, add_l(P1[2], add_l(P2[0], P2[1])), add_l(add_l(P1[0], P1[1]), P2[2])))))
+    zh = (add_l(Z1[0], H[0]), add_l(Z1[1], H[1]))
+    zq0, zqm = mul(add_l(zh[0], zh[1]), sub_k(8, zh[0], zh[1])), mul(zh[0], zh[1])
+    Z3 = (reduce_weak(sub_k(8, zq0, add_l(zz[0], hh[0]))), reduce_weak(dbl_l(sub_k(8, zqm, add_l(zz[1], hh[1])))))
+    return X3 + Y3 + Z3
+
+
+def test_g2_madd_lazy_is_closed_over_safe_inputs():
+    zero = V([0] * 10, 0)
+    s2, c2 = (SAFE, SAFE), (CANON, CANON)
+    neg = (sub_k(4, zero, CANON), sub_k(4, zero, CANON))
+    for y2 in (c2, neg):
+        out = g2_madd_lazy(s2, s2, s2, c2, y2)
+        assert all(o.val <= 3000 and max(o.l[:9]) <= M26 for o in out)
+
+
 def test_reduce_weak_quotient():
     """q = floor(top * RECIP / 2^32) never exceeds floor(x / p) and leaves x - q p < 3p (exhaustive over the top limb edges)."""
     import random

@@ -72,7 +72,7 @@ def test_snark_validation_messages():
 def test_process_batch_consumes_the_batch_even_on_failure():
     b = z.create_proof_batch()
     z.batch_add_improvement_proof(b, 1, 2)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):                            # no GPU in this tier: the product path fails loudly, no CPU fallback
         z.process_batch(b)
     with pytest.raises(ValueError, match="Invalid batch ID"):    # batch.rs:111-118
         z.process_batch(b)
