@@ -18,6 +18,21 @@ Reference lines followed:
   stark.rs:151-186   trace construction and `proof.write_into`
   improvement_proof.rs:10-35, utils/commitment.rs:38-50   payload old || new || stark, SHA-256 binding commitment
 
+Details restated from Winterfell's published design WITHOUT a source or vector to check them against (any of them may
+differ from the crate; none affects soundness, all affect bytes):
+  * coin seed elements: TraceInfo as [(width << 8) | aux segments, trace length], the modulus as two 8-byte halves,
+    options as [(extension << 16) | (folding << 8) | remainder degree, grinding, blowup, queries], then the public inputs;
+  * coin: seed' = H(seed || digest) on reseed, draw = first 16 bytes of H(seed || u64le(++counter)) with rejection of
+    non-canonical values, integers = low bits of the first 8 bytes after seed' = H(seed || u64le(nonce));
+  * coefficient draw order: transition, boundary (step 0, step 7); then z; then one DEEP coefficient per trace column
+    and per composition column; T(z) and T(z g) share one coefficient;
+  * Merkle tree node numbering and the batch-opening node order (one list per opened sibling pair, siblings appended
+    to the list at the same position in each level's index list);
+  * serialisation: context (trace info, modulus, options) | unique query count | commitments (u16 length) | trace
+    queries | constraint queries (each: vint-prefixed values, vint-prefixed opening) | OOD frame (u16-prefixed trace
+    states starting with the frame size 2, u16-prefixed evaluations) | FRI (layer count 0, u16-prefixed remainder,
+    partition count 1) | u64 proof-of-work nonce | one zero byte for the absent GKR proof.
+
 Pipeline (Winterfell's prover, restated): coin seed = BLAKE3(context elements || public inputs) -> interpolate the
 trace column (domain 8) -> evaluate on the LDE coset 3*<w_64> -> hash rows, Merkle root, reseed -> draw 1 transition +
 2 boundary coefficients -> constraint evaluations on the 16-point coset divided by their divisors -> interpolate, keep
