@@ -56,14 +56,14 @@ inline fe host_fe_invert(const fe& z) {   // z^(p-2) = (z^(2^252-3))^8 * z^3
     return fe_mul(t, fe_mul(fe_sq(z), z));
 }
 
-// table[(base*NWIN + w)*NENT + e] = (e+1) * 256^w * Base, affine niels, 30 canonical-limb words each
+// table[(base*NWIN + w)*NENT + e] = (e+1) * 2^(WBITS*w) * Base, affine niels, 30 canonical-limb words each
 inline void host_build_table_for_base(uint32_t* dst, const ge& base) {
     std::vector<ge> pts(NWIN * NENT);
     ge pw = base;
     for (uint32_t w = 0; w < NWIN; w++) {
         ge acc = pw;
         for (uint32_t e = 0; e < NENT; e++) { pts[w * NENT + e] = acc; acc = ge_add(acc, pw); }
-        for (int k = 0; k < 8; k++) pw = ge_dbl(pw);
+        for (uint32_t k = 0; k < WBITS; k++) pw = ge_dbl(pw);
     }
     // batch inversion of Z
     const size_t n = pts.size();
@@ -140,25 +140,25 @@ inline MsmLayout make_layout_even(const std::vector<SlotList>& targets, uint32_t
     return L;
 }
 inline std::vector<SlotList> targets_phase1() {
-    SlotList v = {{BASE_B, 9}, {BASE_BB, 32}}, a = {{BASE_BB, 32}}, s = {{BASE_BB, 32}};
+    SlotList v = {{BASE_B, NWIN_U64}, {BASE_BB, NWIN}}, a = {{BASE_BB, NWIN}}, s = {{BASE_BB, NWIN}};
     for (uint32_t i = 0; i < BP_N; i++) a.push_back({(uint16_t)(BASE_G + i), 1});
     for (uint32_t i = 0; i < BP_N; i++) a.push_back({(uint16_t)(BASE_H + i), 1});
-    for (uint32_t i = 0; i < BP_N; i++) s.push_back({(uint16_t)(BASE_G + i), 32});
-    for (uint32_t i = 0; i < BP_N; i++) s.push_back({(uint16_t)(BASE_H + i), 32});
+    for (uint32_t i = 0; i < BP_N; i++) s.push_back({(uint16_t)(BASE_G + i), NWIN});
+    for (uint32_t i = 0; i < BP_N; i++) s.push_back({(uint16_t)(BASE_H + i), NWIN});
     return {v, a, s};
 }
-inline std::vector<SlotList> targets_phase2() { SlotList t = {{BASE_B, 32}, {BASE_BB, 32}}; return {t, t}; }
+inline std::vector<SlotList> targets_phase2() { SlotList t = {{BASE_B, NWIN}, {BASE_BB, NWIN}}; return {t, t}; }
 inline std::vector<SlotList> targets_round(uint32_t r) {
     const uint32_t p = 5 - r, k = 1u << p;
     auto idx = [&](uint32_t rank, uint32_t bit) { return ((rank >> p) << (p + 1)) | (bit << p) | (rank & (k - 1)); };
-    SlotList l = {{BASE_B, 32}}, rr = {{BASE_B, 32}};
-    for (uint32_t q = 0; q < 32; q++) l.push_back({(uint16_t)(BASE_G + idx(q, 1)), 32});
-    for (uint32_t q = 0; q < 32; q++) l.push_back({(uint16_t)(BASE_H + idx(q, 0)), 32});
-    for (uint32_t q = 0; q < 32; q++) rr.push_back({(uint16_t)(BASE_G + idx(q, 0)), 32});
-    for (uint32_t q = 0; q < 32; q++) rr.push_back({(uint16_t)(BASE_H + idx(q, 1)), 32});
+    SlotList l = {{BASE_B, NWIN}}, rr = {{BASE_B, NWIN}};
+    for (uint32_t q = 0; q < 32; q++) l.push_back({(uint16_t)(BASE_G + idx(q, 1)), NWIN});
+    for (uint32_t q = 0; q < 32; q++) l.push_back({(uint16_t)(BASE_H + idx(q, 0)), NWIN});
+    for (uint32_t q = 0; q < 32; q++) rr.push_back({(uint16_t)(BASE_G + idx(q, 0)), NWIN});
+    for (uint32_t q = 0; q < 32; q++) rr.push_back({(uint16_t)(BASE_H + idx(q, 1)), NWIN});
     return {l, rr};
 }
-inline std::vector<SlotList> targets_ctask() { return {SlotList{{BASE_B, 9}, {BASE_BB, 32}}}; }
+inline std::vector<SlotList> targets_ctask() { return {SlotList{{BASE_B, NWIN_U64}, {BASE_BB, NWIN}}}; }
 inline MsmLayout layout_phase1(uint32_t budget) { return make_layout(targets_phase1(), budget); }
 inline MsmLayout layout_phase2(uint32_t budget) { return make_layout(targets_phase2(), budget); }
 inline MsmLayout layout_round(uint32_t r, uint32_t budget) { return make_layout(targets_round(r), budget); }

@@ -20,7 +20,9 @@ namespace zkp {
 
 constexpr uint32_t BP_N = 64;
 constexpr uint32_t BASE_B = 0, BASE_BB = 1, BASE_G = 2, BASE_H = 66, NBASE = 130;
-constexpr uint32_t NWIN = 32, NENT = 128, NIELS_W = 30, SUBTAB_W = NENT * NIELS_W;
+// fixed-base tables of the 130 generators: signed radix-1024 digits -> 26 windows of 512 affine-niels entries (208 MB);
+// a 64-bit value needs 7 windows.  (The Groth16 key tables use radix 256: G16_* in g16_steps.h.)
+constexpr uint32_t WBITS = 10, NWIN = 26, NENT = 512, DIGW = 13, NWIN_U64 = 7, NIELS_W = 30, SUBTAB_W = NENT * NIELS_W;
 constexpr uint32_t TAPE_SLOTS = 132;
 // phase-1 MSM slots: V = v*B + gamma*B~ ; A = a_bl*B~ + sum bit_i*G_i + (bit_i-1)*H_i ; S = s_bl*B~ + sum sL_i*G_i + sR_i*H_i
 constexpr uint32_t P1_V = 0, P1_A = 2, P1_S = 131, P1_NSLOTS = 260;
@@ -70,10 +72,15 @@ ZKP_HD inline void st_sc(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows,
     uint32_t* q = p + (size_t)idx * 8 * rows + row;
     ZKP_UNROLL for (int k = 0; k < 8; k++) q[(size_t)k * rows] = s.v[k];
 }
-// store the signed radix-256 digits of a Montgomery-form scalar
-ZKP_HD inline void st_digits(uint32_t* d, uint32_t slot, uint32_t row, uint32_t rows, const sc& mont) {
-    sc pk; sc_recode_signed256(pk.v, sc_to_raw(mont));
-    st_sc(d, slot, row, rows, pk);
+// store the signed radix-1024 digits of a raw / Montgomery-form scalar: DIGW words per (slot, row), word-major
+ZKP_HD inline void st_digits_raw(uint32_t* d, uint32_t slot, uint32_t row, uint32_t rows, const sc& raw) {
+    uint32_t pk[DIGW]; sc_recode_signed1024(pk, raw);
+    uint32_t* q = d + (size_t)slot * DIGW * rows + row;
+    ZKP_UNROLL for (uint32_t k = 0; k < DIGW; k++) q[(size_t)k * rows] = pk[k];
+}
+ZKP_HD inline void st_digits(uint32_t* d, uint32_t slot, uint32_t row, uint32_t rows, const sc& mont) { st_digits_raw(d, slot, row, rows, sc_to_raw(mont)); }
+ZKP_HD inline int32_t ld_digit(const uint32_t* d, uint32_t srow, uint32_t w, uint32_t row, uint32_t rows) {
+    return (int32_t)(int16_t)(d[((size_t)srow * DIGW + (w >> 1)) * rows + row] >> (16 * (w & 1u)));
 }
 ZKP_HD inline void put_bytes(uint8_t* dst, const uint32_t* w, int nwords) {
     for (int i = 0; i < nwords; i++) { dst[4 * i] = (uint8_t)w[i]; dst[4 * i + 1] = (uint8_t)(w[i] >> 8); dst[4 * i + 2] = (uint8_t)(w[i] >> 16); dst[4 * i + 3] = (uint8_t)(w[i] >> 24); }
@@ -111,20 +118,19 @@ ZKP_HD inline void step_tape(const BpView& V, uint32_t slot, uint32_t job) {
         st_sc(V.gamma, 0, job, M, g);
         st_digits(V.d1, P1_V + 1, job, M, g);
         const uint64_t v = V.v[job];
-        sc pk; sc_recode_signed256(pk.v, sc_words((uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0));
-        st_sc(V.d1, P1_V + 0, job, M, pk);
-        // A: bit_i * G_i + (bit_i - 1) * H_i  -> single-window digits
+        st_digits_raw(V.d1, P1_V + 0, job, M, sc_words((uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0));
+        // A: bit_i * G_i + (bit_i - 1) * H_i  -> single-window digits (+1 / 0 and 0 / -1)
         for (uint32_t i = 0; i < BP_N; i++) {
             const uint32_t bit = (uint32_t)(v >> i) & 1u;
-            V.d1[(size_t)(P1_A + 1 + i) * 8 * M + job] = bit;
-            V.d1[(size_t)(P1_A + 1 + BP_N + i) * 8 * M + job] = bit ? 0u : 0xFFu;
+            V.d1[(size_t)(P1_A + 1 + i) * DIGW * M + job] = bit;
+            V.d1[(size_t)(P1_A + 1 + BP_N + i) * DIGW * M + job] = bit ? 0u : 0xFFFFu;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // fixed-base MSM, reference per-thread form (table read straight from global memory).
-// table: [NBASE][NWIN][NENT][30] words, entry e = (e+1) * 256^w * Base in affine niels form.
+// table: [NBASE][NWIN][NENT][30] words, entry e = (e+1) * 1024^w * Base in affine niels form.
 ZKP_HD inline ge_niels ld_niels(const uint32_t* p) {
     ge_niels n;
     ZKP_UNROLL for (int k = 0; k < 10; k++) { n.ypx.v[k] = p[k]; n.ymx.v[k] = p[10 + k]; n.xy2d.v[k] = p[20 + k]; }
@@ -154,7 +160,7 @@ ZKP_HD inline ge ld_ge(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t r
 struct MsmView {
     uint32_t rows, nslots, nchunks;
     const uint32_t* table;       // generator tables
-    const uint32_t* digits;      // [nslots][8][rows]
+    const uint32_t* digits;      // [nslots][digit words][rows] (radix 1024: 13 words, radix 256: 8 words per scalar)
     const uint16_t* slot_base;   // [nslots] which table (generator / key point) a slot uses
     const uint16_t* slot_scalar; // [nslots] which digit row a slot reads (nullptr: row = slot)
     const uint8_t* slot_nwin;    // [nslots] number of low windows that may be non-zero
@@ -170,8 +176,7 @@ ZKP_HD inline void msm_chunk_ref(const MsmView& m, uint32_t chunk, uint32_t row)
     uint32_t s = m.chunk_begin[chunk], w = m.chunk_win0[chunk];
     for (uint32_t left = m.chunk_nwin[chunk]; left > 0; left--) {
         const uint32_t srow = m.slot_scalar ? m.slot_scalar[s] : s;
-        const uint32_t word = m.digits[((size_t)srow * 8 + (w >> 2)) * m.rows + row];
-        const int32_t d = (int32_t)(int8_t)(word >> (8 * (w & 3)));
+        const int32_t d = ld_digit(m.digits, srow, w, row, m.rows);
         if (d != 0) acc = msm_accumulate_digit(acc, d, m.table + ((size_t)m.slot_base[s] * NWIN + w) * SUBTAB_W);
         if (++w == m.slot_nwin[s]) { s++; w = 0; }
     }
@@ -389,14 +394,13 @@ ZKP_HD inline void step_transcript_round(const BpView& V, uint32_t r, uint32_t j
 struct CtView {
     uint32_t C;
     const uint64_t* v; const uint32_t* seed_ix; const uint32_t* bl_ix; const uint32_t* seeds;
-    uint32_t* digits;   // [2][8][C]
+    uint32_t* digits;   // [2][DIGW][C]
 };
 ZKP_HD inline void step_ctask(const CtView& T, uint32_t c) {
     uint32_t seed[8]; const uint32_t* p = T.seeds + (size_t)T.seed_ix[c] * 8;
     ZKP_UNROLL for (int k = 0; k < 8; k++) seed[k] = p[k];
     const uint64_t v = T.v[c];
-    sc pk; sc_recode_signed256(pk.v, sc_words((uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0));
-    st_sc(T.digits, 0, c, T.C, pk);
+    st_digits_raw(T.digits, 0, c, T.C, sc_words((uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0));
     st_digits(T.digits, 1, c, T.C, tape_blinding(seed, T.bl_ix[c]));
 }
 

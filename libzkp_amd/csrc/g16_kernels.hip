@@ -3,7 +3,8 @@
 #include "msm_kernel.h"
 
 struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b1/h/l queries)
-    static constexpr uint32_t AFF_W = 20, ACC_W = G1_JAC_W, MIN_WAVES = 4;
+    static constexpr uint32_t AFF_W = 20, ACC_W = G1_JAC_W, MIN_WAVES = 4, TB = 256, NWIN = G16_NWIN, NENT = G16_NENT, DIGW = G16_DIGW, DIG_PER_WORD = 4;
+    static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int8_t)(word >> (8 * (w & 3u))); }
     using Acc = g1_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq>(); }
     static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
@@ -17,7 +18,8 @@ struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b
     static __device__ __forceinline__ Acc add(const Acc& a, const Acc& b) { return jac_add(a, b); }
 };
 struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
-    static constexpr uint32_t AFF_W = 40, ACC_W = G2_JAC_W, MIN_WAVES = 2;
+    static constexpr uint32_t AFF_W = 40, ACC_W = G2_JAC_W, MIN_WAVES = 2, TB = 256, NWIN = G16_NWIN, NENT = G16_NENT, DIGW = G16_DIGW, DIG_PER_WORD = 4;
+    static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int8_t)(word >> (8 * (w & 3u))); }
     using Acc = g2_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq2>(); }
     static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
@@ -67,8 +69,8 @@ __global__ void __launch_bounds__(TW) k_mimc_commit(const uint64_t* values, uint
 template <class F, uint32_t AFF_W>
 __global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, uint32_t nslots, uint32_t* table) {
     const uint32_t t = blockIdx.x * TW + threadIdx.x;
-    if (t >= nslots * NWIN) return;
-    const uint32_t slot = t / NWIN, win = t % NWIN;
+    if (t >= nslots * G16_NWIN) return;
+    const uint32_t slot = t / G16_NWIN, win = t % G16_NWIN;
     constexpr uint32_t FW = AFF_W / 2;
     Aff<F> base;
     {
@@ -79,8 +81,8 @@ __global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, u
     Jac<F> q = jac_from_aff(base);
     for (uint32_t i = 0; i < 8 * win; i++) q = jac_dbl(q);
     Jac<F> acc = q;
-    uint32_t* dst = table + ((size_t)slot * NWIN + win) * NENT * AFF_W;
-    for (uint32_t e = 0; e < NENT; e++) {
+    uint32_t* dst = table + ((size_t)slot * G16_NWIN + win) * G16_NENT * AFF_W;
+    for (uint32_t e = 0; e < G16_NENT; e++) {
         Aff<F> a; jac_to_aff(a, acc);
         const uint32_t* ax = reinterpret_cast<const uint32_t*>(&a.x); const uint32_t* ay = reinterpret_cast<const uint32_t*>(&a.y);
         for (uint32_t k = 0; k < FW; k++) { dst[(size_t)e * AFF_W + k] = ax[k]; dst[(size_t)e * AFF_W + FW + k] = ay[k]; }
@@ -121,14 +123,14 @@ void g16_launch_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* 
 }
 void g16_launch_mimc(const uint64_t* values, uint32_t n, const uint32_t* mimc_c, uint8_t* out, hipStream_t st) { k_mimc_commit<<<(n + TW - 1) / TW, TW, 0, st>>>(values, n, mimc_c, out); }
 void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uint32_t* table, hipStream_t st) {
-    const uint32_t threads = nslots * NWIN;
+    const uint32_t threads = nslots * G16_NWIN;
     if (!g2) k_g16_build_table<fq, 20><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table);
     else k_g16_build_table<fq2, 40><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table);
 }
 void g16_launch_msm(bool g2, const MsmView& m, hipStream_t st) {
-    const uint32_t ngroups = (m.rows + MSM_TB - 1) / MSM_TB, nblocks = m.nchunks * ngroups, grid = ((nblocks + 7) / 8) * 8;
-    if (!g2) k_msm_dma<G1Msm><<<grid, MSM_TB, 0, st>>>(m, ngroups, nblocks);
-    else k_msm_dma<G2Msm><<<grid, MSM_TB, 0, st>>>(m, ngroups, nblocks);
+    const uint32_t ngroups = (m.rows + G1Msm::TB - 1) / G1Msm::TB, nblocks = m.nchunks * ngroups, grid = ((nblocks + 7) / 8) * 8;
+    if (!g2) k_msm_dma<G1Msm><<<grid, G1Msm::TB, msm_lds_bytes<G1Msm>(), st>>>(m, ngroups, nblocks);
+    else k_msm_dma<G2Msm><<<grid, G2Msm::TB, msm_lds_bytes<G2Msm>(), st>>>(m, ngroups, nblocks);
 }
 void g16_launch_sum(bool g2, const ReduceView& R, uint32_t* sums, hipStream_t st) {
     if (!g2) k_sum_t<G1Msm><<<dim3((R.rows + 7) / 8, R.ntargets), TW, 0, st>>>(R, sums);

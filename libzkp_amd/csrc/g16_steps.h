@@ -13,6 +13,10 @@
 
 namespace zkp {
 
+// key-point tables: signed radix-256 digits (8 words per scalar), 32 windows of 128 affine entries
+constexpr uint32_t G16_NWIN = 32, G16_NENT = 128, G16_DIGW = 8;
+
+
 constexpr uint32_t MIMC_ROUNDS = 110, G16_MAX_SET = 64;
 constexpr uint32_t G16_TAPE_IDX = 0x47313600u;
 enum { G16_EQUALITY = 0, G16_MEMBERSHIP = 1 };

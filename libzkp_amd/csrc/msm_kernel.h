@@ -4,7 +4,7 @@
 #include "bp_steps.h"
 
 using namespace zkp;
-static constexpr int MSM_TB = 256;   // lanes (= proofs) per MSM workgroup
+// lanes (= proofs) per MSM workgroup, digit radix and table shape are traits of the point type T (T::TB, T::NWIN, T::NENT, T::DIGW)
 static constexpr int TW = 64;        // one wave per block for per-proof serial steps
 static constexpr int TB = 256;       // threads per block for (i, proof) grids
 
@@ -12,11 +12,13 @@ static constexpr int TB = 256;       // threads per block for (i, proof) grids
 // straight into the other half of a double-buffered LDS image with global_load_lds_dwordx4 (no staging VGPRs, no
 // ds_write) while the current window's point additions run; one barrier per window (after the issuing waves'
 // vmcnt(0)) publishes it.
+template <class T> constexpr size_t msm_lds_bytes() { return (size_t)2 * T::NENT * T::AFF_W * 4; }   // double-buffered sub-table (dynamic LDS)
 template <class T>
-__global__ void __launch_bounds__(MSM_TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint32_t ngroups, uint32_t nblocks) {
+__global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint32_t ngroups, uint32_t nblocks) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins: keep the host-side stub instantiation empty
-    constexpr uint32_t SUB_W = NENT * T::AFF_W, SUB_V4 = SUB_W / 4;
-    __shared__ uint4 lds4[2][SUB_V4];
+    constexpr uint32_t SUB_W = T::NENT * T::AFF_W, SUB_V4 = SUB_W / 4, MSM_TB = T::TB;
+    extern __shared__ uint4 msm_lds4[];
+    uint4* const lds4_0 = msm_lds4;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint32_t per_xcd = (nblocks + 7) / 8;
     const uint32_t linear = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
@@ -28,11 +30,11 @@ __global__ void __launch_bounds__(MSM_TB, T::MIN_WAVES) k_msm_dma(MsmView m, uin
     typename T::Acc acc = m.acc_init ? T::load(m.acc_init, 0, 0, 1) : T::identity();
 #define ZKP_MSM_DMA(buf_, base_, win_)                                                                              \
     do {                                                                                                            \
-        const uint4* src_ = reinterpret_cast<const uint4*>(m.table + ((size_t)(base_) * NWIN + (win_)) * SUB_W);     \
+        const uint4* src_ = reinterpret_cast<const uint4*>(m.table + ((size_t)(base_) * T::NWIN + (win_)) * SUB_W);     \
         ZKP_UNROLL for (uint32_t q_ = 0; q_ < (SUB_V4 + MSM_TB - 1) / MSM_TB; q_++) {                               \
             const uint32_t first_ = q_ * MSM_TB + wave * 64u;   /* wave-uniform: 64 x 16 B = 1 KiB contiguous */    \
             if (first_ < SUB_V4)                                                                                    \
-                __builtin_amdgcn_global_load_lds(src_ + first_ + lane, &lds4[buf_][first_], 16, 0, 0);              \
+                __builtin_amdgcn_global_load_lds(src_ + first_ + lane, lds4_0 + (buf_) * SUB_V4 + first_, 16, 0, 0);              \
         }                                                                                                           \
     } while (0)
     if (left) ZKP_MSM_DMA(0, m.slot_base[s], w);
@@ -45,13 +47,13 @@ __global__ void __launch_bounds__(MSM_TB, T::MIN_WAVES) k_msm_dma(MsmView m, uin
         uint32_t ns = s, nw = w + 1;
         if (nw == nwin) { ns = s + 1; nw = 0; }
         if (left > 1) ZKP_MSM_DMA(cur ^ 1u, m.slot_base[ns], nw);   // lands while this window is being added
-        if ((w & 3u) == 0 || fresh) {
+        if ((w % T::DIG_PER_WORD) == 0 || fresh) {
             fresh = false;
             const uint32_t srow = m.slot_scalar ? m.slot_scalar[s] : s;
-            dw = active ? m.digits[((size_t)srow * 8 + (w >> 2)) * m.rows + row] : 0u;
+            dw = active ? m.digits[((size_t)srow * T::DIGW + w / T::DIG_PER_WORD) * m.rows + row] : 0u;
         }
-        const int32_t d = (int32_t)(int8_t)(dw >> (8 * (w & 3u)));
-        if (d != 0) acc = T::accumulate(acc, d, reinterpret_cast<const uint32_t*>(lds4[cur]));
+        const int32_t d = T::digit(dw, w);
+        if (d != 0) acc = T::accumulate(acc, d, reinterpret_cast<const uint32_t*>(lds4_0 + cur * SUB_V4));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
         __syncthreads();                                   // every wave's pieces landed; every wave is done reading `cur`
         s = ns; w = nw; cur ^= 1u; left--;

@@ -222,4 +222,19 @@ ZKP_HD inline void sc_recode_signed256(uint32_t packed[8], const sc& raw) {
     }
 }
 
+// signed radix-1024 recoding of a canonical raw scalar (< 2^253): 26 digits in [-511, 512], two 16-bit digits per word
+// (13 words).  Used by the Bulletproofs fixed-base tables (512 entries per window, 26 windows).
+ZKP_HD inline void sc_recode_signed1024(uint32_t packed[13], const sc& raw) {
+    uint32_t carry = 0;
+    ZKP_UNROLL for (int j = 0; j < 26; j++) {
+        const int bit = 10 * j, wd = bit >> 5, sh = bit & 31;
+        uint32_t x = wd < 8 ? raw.v[wd] >> sh : 0u;
+        if (sh > 22 && wd + 1 < 8) x |= raw.v[wd + 1] << (32 - sh);
+        uint32_t d = (x & 0x3ffu) + carry;                          // 0..1024
+        carry = d > 512u ? 1u : 0u;                                 // digit = d - 1024*carry in [-511, 512]
+        d = (d - (carry << 10)) & 0xffffu;
+        if ((j & 1) == 0) packed[j >> 1] = d; else packed[j >> 1] |= d << 16;
+    }
+}
+
 }  // namespace zkp

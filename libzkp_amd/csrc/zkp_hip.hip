@@ -14,6 +14,7 @@
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <sys/random.h>
 #include "bp_layout.h"
 #include "g16_steps.h"
@@ -92,14 +93,17 @@ __global__ void __launch_bounds__(TW) k_encode(ReduceView R, const uint32_t* sum
 
 // ------------------------------------------------------------------------------------------------
 // Fixed-base multiscalar multiplication, lane = proof (kernel template: msm_kernel.h).
-//   grid  : nchunks * ngroups workgroups of MSM_TB lanes; a workgroup owns one chunk of (slot, window) steps (same
-//           generators for all its lanes) and MSM_TB consecutive proofs.
-//   LDS   : the 15 KB sub-table (128 affine-niels multiples of 256^w * Base) of the current and the next step,
-//           filled by LDS-DMA, gathered per lane by its own signed digit.
+//   grid  : nchunks * ngroups workgroups of 1024 lanes; a workgroup owns one chunk of (slot, window) steps (same
+//           generators for all its lanes) and 1024 consecutive proofs: 16 waves = 4 per SIMD, one workgroup per CU.
+//   LDS   : the 60 KB sub-table (512 affine-niels multiples of 1024^w * Base) of the current and the next step
+//           (120 KB, dynamic), filled by LDS-DMA, gathered per lane by its own signed radix-1024 digit.  Radix 1024
+//           needs 26 additions per 253-bit scalar where radix 256 needed 32; the sub-table is four times larger, which
+//           is why the workgroup is four times wider (same 60 B of table traffic per addition).
 //   XCD   : workgroups that share a chunk (hence the same sub-tables) are mapped onto the same XCD so the sub-table
 //           stays in that XCD's 4 MB L2 (blocks b and b+8 share an XCD).
 struct EdMsm {      // edwards25519 affine-Niels tables, extended-coordinate accumulator (Bulletproofs path)
-    static constexpr uint32_t AFF_W = NIELS_W, ACC_W = GE_W, MIN_WAVES = 4;
+    static constexpr uint32_t AFF_W = NIELS_W, ACC_W = GE_W, MIN_WAVES = 4, TB = 1024, NWIN = zkp::NWIN, NENT = zkp::NENT, DIGW = zkp::DIGW, DIG_PER_WORD = 2;
+    static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int16_t)(word >> (16 * (w & 1u))); }
     using Acc = ge;
     static __device__ __forceinline__ Acc identity() { return ge_identity(); }
     static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) { return msm_accumulate_digit(acc, d, subtab); }
@@ -159,7 +163,7 @@ struct Ctx {
 Ctx g;
 std::mutex g_mu;
 uint32_t g_budget_request = 0;     // 0 = choose per launch
-double g_fill = 2.0;               // grid size target in units of resident workgroups
+double g_fill = 1.0;               // benchmarking knob: scales the resident-workgroup count the Bulletproofs MSM chunking aims at
 uint32_t g_subbatches = 1;         // >1: independent slices on separate streams (measured slower on MI355X: see DESIGN.md)
 
 int upload_layout(DevLayout& D, const MsmLayout& L) {
@@ -199,7 +203,7 @@ int upload_set(LayoutSet& S, const std::vector<SlotList>& targets) {
         return 0;
     };
     for (int T = 1; T <= MAXT; T++) { int rc = push(make_layout(targets, 32u * T)); if (rc) return rc; }
-    static const uint32_t counts[] = {3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 160, 192, 256, 384, 512};
+    static const uint32_t counts[] = {3, 4, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 36, 40, 42, 48, 51, 56, 64, 72, 80, 85, 96, 112, 128, 144, 160, 192, 224, 256, 320, 384, 448, 512};
     for (uint32_t c : counts) { if (c > total || c < targets.size()) continue; int rc = push(make_layout_even(targets, c)); if (rc) return rc; }
     return 0;
 }
@@ -214,19 +218,20 @@ const DevLayout& pick_layout(const LayoutSet& S, uint32_t rows) {
         return S.cand[best < S.cand.size() ? best : 0];
     }
     if (g_budget_request) { int T = (int)(g_budget_request / 32); if (T < 1) T = 1; if (T > MAXT) T = MAXT; return S.cand[T - 1]; }
-    // Measured on MI355X: with workgroups dispatched dynamically the MSM time is flat once the grid holds
-    // about twice the resident workgroup count, while every extra chunk costs partial-sum work; so take the window-
-    // granular layout with the fewest chunks that still gives >= g_fill x resident workgroups.
-    const double resident = (double)g.num_cu * g.msm_blocks_per_cu;
-    const uint32_t groups = (rows + 255) / 256;
-    size_t best = S.cand.size() - 1; uint32_t best_chunks = 0xffffffffu; bool found = false;
-    size_t most = MAXT; uint32_t most_chunks = 0;
+    // One 1024-lane workgroup fills a CU (16 waves, 120 KB LDS), so the grid runs in strict rounds of `resident` equal
+    // workgroups (measured: 1.5 rounds cost 1.30x of 1 round, 2 rounds 1.00x with half-size chunks).  Take the window-
+    // granular layout that minimises rounds x (windows per workgroup + per-workgroup overhead) + the partial-sum work
+    // that grows with the chunk count; g_fill scales the resident count (benchmarking knob, default 1).
+    const double resident = g_fill * (double)g.num_cu * g.msm_blocks_per_cu;
+    const uint32_t groups = (rows + EdMsm::TB - 1) / EdMsm::TB;
+    size_t best = MAXT; double best_cost = 1e300;
     for (size_t i = MAXT; i < S.cand.size(); i++) {
         const uint32_t nc = S.cand[i].nchunks;
-        if (nc > most_chunks) { most_chunks = nc; most = i; }
-        if ((double)nc * groups >= g_fill * resident && nc < best_chunks) { best_chunks = nc; best = i; found = true; }
+        const double rounds = std::ceil((double)nc * groups / resident);
+        const double cost = rounds * ((double)S.cand[i].max_chunk_windows + 1.5) + 0.25 * nc / 8.0;
+        if (cost < best_cost) { best_cost = cost; best = i; }
     }
-    return S.cand[found ? best : most];
+    return S.cand[best < S.cand.size() ? best : 0];
 }
 
 int init_locked(int device) {
@@ -243,7 +248,9 @@ int init_locked(int device) {
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
     g.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_msm_dma<EdMsm>, MSM_TB, 0) == hipSuccess && occ > 0) g.msm_blocks_per_cu = occ;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<EdMsm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<EdMsm>()));
+    g.msm_blocks_per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_msm_dma<EdMsm>, EdMsm::TB, msm_lds_bytes<EdMsm>()) == hipSuccess && occ > 0) g.msm_blocks_per_cu = occ;
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&g.start_ev, hipEventDisableTiming));
     // generator tables (one-time, host)
@@ -293,6 +300,7 @@ size_t carve(uint8_t* base, uint32_t M, uint32_t C, uint32_t max_chunks, Ws* w) 
     size_t off = 0;
     auto take = [&](size_t bytes) { uint8_t* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
     const size_t W = (size_t)8 * 4 * M;   // one scalar slot for all jobs
+    const size_t WD = (size_t)DIGW * 4 * M;   // one digit slot (signed radix-1024 digits of one scalar) for all jobs
     Ws t{};
     t.J.v = (uint64_t*)take(8ull * M); t.J.seed_ix = (uint32_t*)take(4ull * M); t.J.proof_ix = (uint32_t*)take(4ull * M);
     t.J.bl_plus = (int32_t*)take(4ull * M); t.J.bl_minus = (int32_t*)take(4ull * M); t.J.kind = (uint8_t*)take(M);
@@ -301,14 +309,14 @@ size_t carve(uint8_t* base, uint32_t M, uint32_t C, uint32_t max_chunks, Ws* w) 
     t.V.M = M; t.V.v = t.J.v; t.V.seed_ix = t.J.seed_ix; t.V.proof_ix = t.J.proof_ix; t.V.bl_plus = t.J.bl_plus; t.V.bl_minus = t.J.bl_minus;
     t.V.kind = t.J.kind; t.V.proof_off = t.J.proof_off; t.V.commit_off = t.J.commit_off;
     t.V.tape = (uint32_t*)take(W * TAPE_SLOTS); t.V.gamma = (uint32_t*)take(W);
-    t.V.d1 = (uint32_t*)take(W * P1_NSLOTS); t.V.d2 = (uint32_t*)take(W * P2_NSLOTS); t.V.dr = (uint32_t*)take(W * PR_NSLOTS);
+    t.V.d1 = (uint32_t*)take(WD * P1_NSLOTS); t.V.d2 = (uint32_t*)take(WD * P2_NSLOTS); t.V.dr = (uint32_t*)take(WD * PR_NSLOTS);
     t.V.ypow = (uint32_t*)take(W * 64); t.V.yinvpow = (uint32_t*)take(W * 64); t.V.r0 = (uint32_t*)take(W * 64); t.V.r1 = (uint32_t*)take(W * 64);
     t.V.pp = (uint32_t*)take(W * 192); t.V.ab = (uint32_t*)take(W * 256); t.V.gh = (uint32_t*)take(W * 128);
     t.V.scal = (uint32_t*)take(W * SC_NUM); t.V.tstate = (uint32_t*)take(4ull * 52 * M); t.V.enc = (uint32_t*)take(W * 3);
     t.partial = (uint32_t*)take((size_t)max_chunks * GE_W * 4 * M);
     t.sums = (uint32_t*)take((size_t)3 * GE_W * 4 * M);
     t.T.C = C; t.T.v = t.J.ct_v; t.T.seed_ix = t.J.ct_seed_ix; t.T.bl_ix = t.J.ct_bl_ix;
-    t.T.digits = (uint32_t*)take((size_t)2 * 8 * 4 * C);
+    t.T.digits = (uint32_t*)take((size_t)2 * DIGW * 4 * C);
     t.ct_partial = (uint32_t*)take((size_t)(g.ct.max_chunks ? g.ct.max_chunks : 2) * GE_W * 4 * C);
     t.ct_enc = (uint32_t*)take((size_t)8 * 4 * C);
     t.ct_sums = (uint32_t*)take((size_t)GE_W * 4 * C);
@@ -331,7 +339,7 @@ int ensure_workspace(SubBatch& sb, uint32_t M, uint32_t C) {
 int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32_t* partial, hipStream_t st) {
     MsmView m; m.rows = rows; m.nslots = D.nslots; m.nchunks = D.nchunks; m.table = g.d_table; m.digits = digits;
     m.slot_base = D.slot_base; m.slot_scalar = nullptr; m.slot_nwin = D.slot_nwin; m.chunk_begin = D.chunk_begin; m.chunk_win0 = D.chunk_win0; m.chunk_nwin = D.chunk_nwin; m.partial = partial; m.acc_init = nullptr;
-    const uint32_t ngroups = (rows + MSM_TB - 1) / MSM_TB, nblocks = D.nchunks * ngroups;
+    const uint32_t ngroups = (rows + EdMsm::TB - 1) / EdMsm::TB, nblocks = D.nchunks * ngroups;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g.profiling) {
@@ -341,7 +349,7 @@ int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32
         e0 = g.ev_pool[g.ev_used].first; e1 = g.ev_pool[g.ev_used].second; g.ev_used++;
         HIP_TRY(hipEventRecord(e0, st));
     }
-    k_msm_dma<EdMsm><<<grid, MSM_TB, 0, st>>>(m, ngroups, nblocks);
+    k_msm_dma<EdMsm><<<grid, EdMsm::TB, msm_lds_bytes<EdMsm>(), st>>>(m, ngroups, nblocks);
     if (g.profiling) { HIP_TRY(hipEventRecord(e1, st)); g.msm_launches++; g.msm_adds += D.adds_per_row * rows; }
     return 0;
 }

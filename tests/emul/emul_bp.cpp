@@ -44,7 +44,9 @@ int emul_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* mn
     for (uint32_t op = 0; op < n; op++) step_build_range(J, op, value, mn, mx, out, stride, out_len, status);
     std::vector<uint32_t> seedw(8 * n); memcpy(seedw.data(), seeds, 32 * n);
     auto words = [&](size_t k) { return std::vector<uint32_t>(k * 8 * M, 0xDEADBEEFu); };
-    auto tape = words(TAPE_SLOTS), gamma = words(1), d1 = words(P1_NSLOTS), d2 = words(P2_NSLOTS), dr = words(PR_NSLOTS), ypow = words(64), yinv = words(64),
+    auto dwords = [&](size_t k) { return std::vector<uint32_t>(k * DIGW * M, 0xDEADBEEFu); };
+    auto d1 = dwords(P1_NSLOTS), d2 = dwords(P2_NSLOTS), dr = dwords(PR_NSLOTS);
+    auto tape = words(TAPE_SLOTS), gamma = words(1), ypow = words(64), yinv = words(64),
          r0 = words(64), r1 = words(64), pp = words(192), ab = words(256), gh = words(128), scal = words(SC_NUM), enc = words(3);
     std::vector<uint32_t> tstate((size_t)52 * M);
     BpView V; V.M = M; V.v = v.data(); V.seed_ix = six.data(); V.proof_ix = pix.data(); V.bl_plus = blp.data(); V.bl_minus = blm.data(); V.kind = kind.data();
@@ -55,7 +57,7 @@ int emul_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* mn
     uint32_t st[50]; Strobe s; s.base = st; s.stride = 1;
 
     // commitment tasks
-    std::vector<uint32_t> ctd((size_t)2 * 8 * C), ctenc((size_t)8 * C);
+    std::vector<uint32_t> ctd((size_t)2 * DIGW * C), ctenc((size_t)8 * C);
     CtView T{C, ctv.data(), ctsix.data(), ctbl.data(), seedw.data(), ctd.data()};
     for (uint32_t c = 0; c < C; c++) step_ctask(T, c);
     const bool even = win_budget >= 10000; const uint32_t nch = win_budget - 10000;

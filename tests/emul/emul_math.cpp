@@ -44,6 +44,9 @@ void emul_sc_from_wide(const uint32_t w[16], uint32_t out[8]) { sc r = sc_to_raw
 void emul_sc_recode(const uint32_t a[8], int8_t digits[32]) {
     sc x; memcpy(x.v, a, 32); uint32_t p[8]; sc_recode_signed256(p, x); memcpy(digits, p, 32);
 }
+void emul_sc_recode1024(const uint32_t a[8], int16_t digits[26]) {
+    sc x; memcpy(x.v, a, 32); uint32_t p[13]; sc_recode_signed1024(p, x); memcpy(digits, p, 52);
+}
 void emul_tape_draw64(const uint32_t seed[8], uint32_t pidx, uint32_t slot, uint32_t out[16]) { tape_draw64(out, seed, pidx, slot); }
 void emul_from_uniform_encode(const uint32_t w[16], uint32_t out[8]) { ge p = ge_from_uniform_words(w); ge_ristretto_encode(out, p); }
 // encode(a*P + b*Q) where P, Q = from_uniform(w1), from_uniform(w2); a, b small ints via repeated add/dbl

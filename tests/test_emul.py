@@ -61,6 +61,9 @@ def test_scalars(emul):
         dg = (ctypes.c_int8 * 32)()
         lib.emul_sc_recode(W(a), dg)
         assert sum(int(dg[k]) << (8 * k) for k in range(32)) == a
+        dg10 = (ctypes.c_int16 * 26)()
+        lib.emul_sc_recode1024(W(a), dg10)
+        assert sum(int(dg10[k]) << (10 * k) for k in range(26)) == a and all(-511 <= int(x) <= 512 for x in dg10)
     for x in [0, 2**512 - 1, 2**256, LL * LL] + [rnd.randrange(2**512) for _ in range(50)]:
         lib.emul_sc_from_wide(W(x, 16), out)
         assert I(out) == x % LL
