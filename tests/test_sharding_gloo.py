@@ -48,8 +48,12 @@ WORKER = textwrap.dedent("""
 def test_world_size_two_gloo(tmp_path, oracle_c):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    import socket
+    with socket.socket() as sk:                      # a free rendezvous port (a fixed one can still be in TIME_WAIT from the previous run)
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29611", str(script)], env=env, capture_output=True, text=True, timeout=600)
+                          "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
