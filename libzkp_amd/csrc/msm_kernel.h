@@ -37,26 +37,29 @@ __global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint
                 __builtin_amdgcn_global_load_lds(src_ + first_ + lane, lds4_0 + (buf_) * SUB_V4 + first_, 16, 0, 0);              \
         }                                                                                                           \
     } while (0)
+    // digit words are fetched one step ahead: the load rides under the same vmcnt(0) + barrier that publishes the sub-table
+    auto digit_word = [&](uint32_t slot, uint32_t win) -> uint32_t {
+        const uint32_t srow = m.slot_scalar ? m.slot_scalar[slot] : slot;
+        return active ? m.digits[((size_t)srow * T::DIGW + win / T::DIG_PER_WORD) * m.rows + row] : 0u;
+    };
     if (left) ZKP_MSM_DMA(0, m.slot_base[s], w);
+    uint32_t dw = left ? digit_word(s, w) : 0u;                   // the chunk may start in the middle of a word
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    uint32_t dw = 0;
-    bool fresh = true;                                            // first window of the chunk may start mid-word
     while (left) {
         const uint32_t nwin = m.slot_nwin[s];
         uint32_t ns = s, nw = w + 1;
         if (nw == nwin) { ns = s + 1; nw = 0; }
-        if (left > 1) ZKP_MSM_DMA(cur ^ 1u, m.slot_base[ns], nw);   // lands while this window is being added
-        if ((w % T::DIG_PER_WORD) == 0 || fresh) {
-            fresh = false;
-            const uint32_t srow = m.slot_scalar ? m.slot_scalar[s] : s;
-            dw = active ? m.digits[((size_t)srow * T::DIGW + w / T::DIG_PER_WORD) * m.rows + row] : 0u;
+        uint32_t dnext = dw;
+        if (left > 1) {
+            ZKP_MSM_DMA(cur ^ 1u, m.slot_base[ns], nw);           // lands while this window is being added
+            if ((nw % T::DIG_PER_WORD) == 0) dnext = digit_word(ns, nw);
         }
         const int32_t d = T::digit(dw, w);
         if (d != 0) acc = T::accumulate(acc, d, reinterpret_cast<const uint32_t*>(lds4_0 + cur * SUB_V4));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces (and the prefetched digit word) have landed
         __syncthreads();                                   // every wave's pieces landed; every wave is done reading `cur`
-        s = ns; w = nw; cur ^= 1u; left--;
+        s = ns; w = nw; cur ^= 1u; left--; dw = dnext;
     }
 #undef ZKP_MSM_DMA
     if (active) T::store(m.partial, chunk, row, m.rows, acc);
