@@ -18,7 +18,8 @@ def main():
     for p in pmcs:
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(p)):
-            agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            name = r["Kernel_Name"].split("(")[0]
+            agg[name[5:] if name.startswith("void ") else name][r["Counter_Name"]].append(float(r["Counter_Value"]))
         lines += ["", "## --pmc pass (%s): per-dispatch averages" % p, ""]
         for k in sorted(agg):
             if not k.startswith("k_"):
