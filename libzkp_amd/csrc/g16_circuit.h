@@ -61,29 +61,29 @@ inline HostLC r1cs_mimc(HostR1CS& cs, HostLC x) {                   // snark.rs:
     ensure_mimc_constants();
     for (uint32_t i = 0; i < MIMC_ROUNDS; i++) {
         const HostLC t = lc_add(x, lc_scale(lc_var(VAR_ONE), g_mimc_host[i]));
-        const uint32_t t2 = r1cs_mul(cs, t, t, 32);
-        const uint32_t t4 = r1cs_mul(cs, lc_var(t2), lc_var(t2), 32);
-        x = lc_var(r1cs_mul(cs, lc_var(t4), t, 32));
+        const uint32_t t2 = r1cs_mul(cs, t, t, G16_NWIN);
+        const uint32_t t4 = r1cs_mul(cs, lc_var(t2), lc_var(t2), G16_NWIN);
+        x = lc_var(r1cs_mul(cs, lc_var(t4), t, G16_NWIN));
     }
     return x;
 }
 inline HostR1CS build_equality_r1cs() {                              // snark.rs:262-291
     HostR1CS cs;
-    const uint32_t a = cs.new_witness(9), b = cs.new_witness(9);
+    const uint32_t a = cs.new_witness(G16_NWIN_U64), b = cs.new_witness(G16_NWIN_U64);
     r1cs_enforce_equal(cs, lc_var(a), lc_var(b));
     const HostLC h = r1cs_mimc(cs, lc_var(a));
-    const uint32_t c = cs.new_input(32);
+    const uint32_t c = cs.new_input(G16_NWIN);
     r1cs_enforce_equal(cs, h, lc_var(c));
     return cs;
 }
 inline HostR1CS build_membership_r1cs() {                            // snark.rs:514-585
     HostR1CS cs;
-    const uint32_t v = cs.new_witness(9);
+    const uint32_t v = cs.new_witness(G16_NWIN_U64);
     const HostLC h = r1cs_mimc(cs, lc_var(v));
-    const uint32_t c = cs.new_input(32);
+    const uint32_t c = cs.new_input(G16_NWIN);
     r1cs_enforce_equal(cs, h, lc_var(c));
     std::vector<uint32_t> setv, real, sel;
-    for (uint32_t i = 0; i < G16_MAX_SET; i++) setv.push_back(cs.new_input(9));
+    for (uint32_t i = 0; i < G16_MAX_SET; i++) setv.push_back(cs.new_input(G16_NWIN_U64));
     for (uint32_t i = 0; i < G16_MAX_SET; i++) { const uint32_t b = cs.new_input(1); cs.rows.push_back({lc_sub(lc_var(VAR_ONE), lc_var(b)), lc_var(b), HostLC{}}); real.push_back(b); }
     for (uint32_t i = 0; i < G16_MAX_SET; i++) { const uint32_t b = cs.new_witness(1); cs.rows.push_back({lc_sub(lc_var(VAR_ONE), lc_var(b)), lc_var(b), HostLC{}}); sel.push_back(b); }
     HostLC total;
@@ -94,7 +94,7 @@ inline HostR1CS build_membership_r1cs() {                            // snark.rs
     }
     r1cs_enforce_equal(cs, total, lc_var(VAR_ONE));
     HostLC acc;
-    for (uint32_t i = 0; i < G16_MAX_SET; i++) acc = lc_add(acc, lc_var(r1cs_mul(cs, lc_var(sel[i]), lc_sub(lc_var(v), lc_var(setv[i])), 32)));
+    for (uint32_t i = 0; i < G16_MAX_SET; i++) acc = lc_add(acc, lc_var(r1cs_mul(cs, lc_var(sel[i]), lc_sub(lc_var(v), lc_var(setv[i])), G16_NWIN)));
     r1cs_enforce_equal(cs, acc, HostLC{});
     return cs;
 }

@@ -3,8 +3,9 @@
 #include "msm_kernel.h"
 
 struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b1/h/l queries)
-    static constexpr uint32_t AFF_W = 20, ACC_W = G1_JAC_W, MIN_WAVES = 4, TB = 256, NWIN = G16_NWIN, NENT = G16_NENT, DIGW = G16_DIGW, DIG_PER_WORD = 4;
-    static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int8_t)(word >> (8 * (w & 3u))); }
+    static constexpr uint32_t AFF_W = 20, ACC_W = G1_JAC_W, MIN_WAVES = 4, TB = 1024, NWIN = G16_NWIN, NENT = G16_NENT, DIGW = G16_DIGW, DIG_PER_WORD = 2;
+    static constexpr bool DOUBLE_BUF = true;                      // 2 x 40 KB sub-table images, one 1024-lane workgroup per CU
+    static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int16_t)(word >> (16 * (w & 1u))); }
     using Acc = g1_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq>(); }
     static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
@@ -18,8 +19,9 @@ struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b
     static __device__ __forceinline__ Acc add(const Acc& a, const Acc& b) { return jac_add(a, b); }
 };
 struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
-    static constexpr uint32_t AFF_W = 40, ACC_W = G2_JAC_W, MIN_WAVES = 2, TB = 256, NWIN = G16_NWIN, NENT = G16_NENT, DIGW = G16_DIGW, DIG_PER_WORD = 4;
-    static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int8_t)(word >> (8 * (w & 3u))); }
+    static constexpr uint32_t AFF_W = 40, ACC_W = G2_JAC_W, MIN_WAVES = 2, TB = 512, NWIN = G16_NWIN, NENT = G16_NENT, DIGW = G16_DIGW, DIG_PER_WORD = 2;
+    static constexpr bool DOUBLE_BUF = false;                     // one 80 KB image (two would need all 160 KB of LDS); 512 lanes = 2 waves/SIMD at 256 VGPRs
+    static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int16_t)(word >> (16 * (w & 1u))); }
     using Acc = g2_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq2>(); }
     static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
@@ -65,7 +67,7 @@ __global__ void __launch_bounds__(TW) k_mimc_commit(const uint64_t* values, uint
     uint32_t w[8]; fp_to_raw(w, h);
     g16_put_bytes(out + 32ull * i, w, 8);
 }
-// thread = (slot, window): entries e = 1..128 of 256^window * Base as affine points (Montgomery coordinates)
+// thread = (slot, window): entries e = 1..512 of 1024^window * Base as affine points (Montgomery coordinates)
 template <class F, uint32_t AFF_W>
 __global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, uint32_t nslots, uint32_t* table) {
     const uint32_t t = blockIdx.x * TW + threadIdx.x;
@@ -79,7 +81,7 @@ __global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, u
         for (uint32_t k = 0; k < FW; k++) { bx[k] = b[k]; by[k] = b[FW + k]; }
     }
     Jac<F> q = jac_from_aff(base);
-    for (uint32_t i = 0; i < 8 * win; i++) q = jac_dbl(q);
+    for (uint32_t i = 0; i < G16_WBITS * win; i++) q = jac_dbl(q);
     Jac<F> acc = q;
     uint32_t* dst = table + ((size_t)slot * G16_NWIN + win) * G16_NENT * AFF_W;
     for (uint32_t e = 0; e < G16_NENT; e++) {
@@ -128,7 +130,14 @@ void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uin
     else k_g16_build_table<fq2, 40><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table);
 }
 void g16_launch_msm(bool g2, const MsmView& m, hipStream_t st) {
-    const uint32_t ngroups = (m.rows + G1Msm::TB - 1) / G1Msm::TB, nblocks = m.nchunks * ngroups, grid = ((nblocks + 7) / 8) * 8;
+    const uint32_t tb = g2 ? G2Msm::TB : G1Msm::TB;
+    const uint32_t ngroups = (m.rows + tb - 1) / tb, nblocks = m.nchunks * ngroups, grid = ((nblocks + 7) / 8) * 8;
+    static bool attr_set = false;
+    if (!attr_set) {       // > 64 KB of dynamic LDS needs the opt-in attribute
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<G1Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<G1Msm>());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<G2Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<G2Msm>());
+        attr_set = true;
+    }
     if (!g2) k_msm_dma<G1Msm><<<grid, G1Msm::TB, msm_lds_bytes<G1Msm>(), st>>>(m, ngroups, nblocks);
     else k_msm_dma<G2Msm><<<grid, G2Msm::TB, msm_lds_bytes<G2Msm>(), st>>>(m, ngroups, nblocks);
 }

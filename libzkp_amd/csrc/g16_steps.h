@@ -13,8 +13,9 @@
 
 namespace zkp {
 
-// key-point tables: signed radix-256 digits (8 words per scalar), 32 windows of 128 affine entries
-constexpr uint32_t G16_NWIN = 32, G16_NENT = 128, G16_DIGW = 8;
+// key-point tables: signed radix-1024 digits (13 words per scalar, two 16-bit digits per word), 26 windows of 512 affine
+// entries; a 64-bit value needs 7 windows
+constexpr uint32_t G16_WBITS = 10, G16_NWIN = 26, G16_NENT = 512, G16_DIGW = 13, G16_NWIN_U64 = 7;
 
 
 constexpr uint32_t MIMC_ROUNDS = 110, G16_MAX_SET = 64;
@@ -34,12 +35,12 @@ ZKP_HD inline fr ld_fr_c(const uint32_t* p, uint32_t idx) { fr r; ZKP_UNROLL for
 ZKP_HD inline void g16_put_bytes(uint8_t* dst, const uint32_t* w, int nwords) {
     for (int i = 0; i < nwords; i++) { dst[4 * i] = (uint8_t)w[i]; dst[4 * i + 1] = (uint8_t)(w[i] >> 8); dst[4 * i + 2] = (uint8_t)(w[i] >> 16); dst[4 * i + 3] = (uint8_t)(w[i] >> 24); }
 }
-// packed signed radix-256 digits of a Montgomery-form Fr element (canonical value < r < 2^254: 32 windows)
+// packed signed radix-1024 digits of a Montgomery-form Fr element (canonical value < r < 2^254: 26 windows)
 ZKP_HD inline void st_fr_digits(uint32_t* d, uint32_t idx, uint32_t row, uint32_t rows, const fr& x) {
     sc raw; fp_to_raw(raw.v, x);
-    sc pk; sc_recode_signed256(pk.v, raw);
-    uint32_t* q = d + (size_t)idx * 8 * rows + row;
-    ZKP_UNROLL for (int k = 0; k < 8; k++) q[(size_t)k * rows] = pk.v[k];
+    uint32_t pk[G16_DIGW]; sc_recode_signed1024(pk, raw);
+    uint32_t* q = d + (size_t)idx * G16_DIGW * rows + row;
+    ZKP_UNROLL for (uint32_t k = 0; k < G16_DIGW; k++) q[(size_t)k * rows] = pk[k];
 }
 
 struct G16View {
@@ -53,7 +54,7 @@ struct G16View {
     const uint32_t* mimc_c;                   // [110][8] round constants (Montgomery Fr)
     // workspace
     uint32_t* z;                              // [nv][8][rows] full assignment (instance block first), Montgomery Fr
-    uint32_t* sdig;                           // [nscalars][8][rows] packed digits: z_k (nv), h_i (m-1), r, s, -rs, one
+    uint32_t* sdig;                           // [nscalars][G16_DIGW][rows] packed digits: z_k (nv), h_i (m-1), r, s, -rs, one
     uint32_t* rs;                             // [2][8][rows] raw canonical r, s (for the variable-base part of C)
     // output
     uint8_t* out; uint64_t stride;            // envelope per row
@@ -131,8 +132,8 @@ ZKP_HD inline void step_g16_witness(const G16View& V, uint32_t row) {
     st_fr_digits(V.sdig, g16_sc_r(V), row, rows, r);
     st_fr_digits(V.sdig, g16_sc_s(V), row, rows, s);
     st_fr_digits(V.sdig, g16_sc_nrs(V), row, rows, fp_neg(fp_mul(r, s)));
-    uint32_t* q = V.sdig + (size_t)g16_sc_one(V) * 8 * rows + row;
-    q[0] = 1u; for (int k = 1; k < 8; k++) q[(size_t)k * rows] = 0u;
+    uint32_t* q = V.sdig + (size_t)g16_sc_one(V) * G16_DIGW * rows + row;
+    q[0] = 1u; for (uint32_t k = 1; k < G16_DIGW; k++) q[(size_t)k * rows] = 0u;
     fr rr, sr; fp_to_raw(rr.v, r); fp_to_raw(sr.v, s);
     st_fr(V.rs, 0, row, rows, rr); st_fr(V.rs, 1, row, rows, sr);
 }

@@ -12,7 +12,7 @@ static constexpr int TB = 256;       // threads per block for (i, proof) grids
 // straight into the other half of a double-buffered LDS image with global_load_lds_dwordx4 (no staging VGPRs, no
 // ds_write) while the current window's point additions run; one barrier per window (after the issuing waves'
 // vmcnt(0)) publishes it.
-template <class T> constexpr size_t msm_lds_bytes() { return (size_t)2 * T::NENT * T::AFF_W * 4; }   // double-buffered sub-table (dynamic LDS)
+template <class T> constexpr size_t msm_lds_bytes() { return (size_t)(T::DOUBLE_BUF ? 2 : 1) * T::NENT * T::AFF_W * 4; }   // sub-table image(s), dynamic LDS
 template <class T>
 __global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint32_t ngroups, uint32_t nblocks) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins: keep the host-side stub instantiation empty
@@ -51,15 +51,25 @@ __global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint
         uint32_t ns = s, nw = w + 1;
         if (nw == nwin) { ns = s + 1; nw = 0; }
         uint32_t dnext = dw;
-        if (left > 1) {
-            ZKP_MSM_DMA(cur ^ 1u, m.slot_base[ns], nw);           // lands while this window is being added
-            if ((nw % T::DIG_PER_WORD) == 0) dnext = digit_word(ns, nw);
-        }
         const int32_t d = T::digit(dw, w);
-        if (d != 0) acc = T::accumulate(acc, d, reinterpret_cast<const uint32_t*>(lds4_0 + cur * SUB_V4));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces (and the prefetched digit word) have landed
-        __syncthreads();                                   // every wave's pieces landed; every wave is done reading `cur`
-        s = ns; w = nw; cur ^= 1u; left--; dw = dnext;
+        if constexpr (T::DOUBLE_BUF) {
+            if (left > 1) {
+                ZKP_MSM_DMA(cur ^ 1u, m.slot_base[ns], nw);           // lands while this window is being added
+                if ((nw % T::DIG_PER_WORD) == 0) dnext = digit_word(ns, nw);
+            }
+            if (d != 0) acc = T::accumulate(acc, d, reinterpret_cast<const uint32_t*>(lds4_0 + cur * SUB_V4));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces (and the prefetched digit word) have landed
+            __syncthreads();                                   // every wave's pieces landed; every wave is done reading `cur`
+            cur ^= 1u;
+        } else {                                               // one sub-table image (it does not fit twice): refill between windows
+            if (left > 1 && (nw % T::DIG_PER_WORD) == 0) dnext = digit_word(ns, nw);
+            if (d != 0) acc = T::accumulate(acc, d, reinterpret_cast<const uint32_t*>(lds4_0));
+            __syncthreads();                                   // every wave is done reading the image
+            if (left > 1) ZKP_MSM_DMA(0u, m.slot_base[ns], nw);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        s = ns; w = nw; left--; dw = dnext;
     }
 #undef ZKP_MSM_DMA
     if (active) T::store(m.partial, chunk, row, m.rows, acc);

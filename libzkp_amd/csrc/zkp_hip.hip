@@ -103,6 +103,7 @@ __global__ void __launch_bounds__(TW) k_encode(ReduceView R, const uint32_t* sum
 //           stays in that XCD's 4 MB L2 (blocks b and b+8 share an XCD).
 struct EdMsm {      // edwards25519 affine-Niels tables, extended-coordinate accumulator (Bulletproofs path)
     static constexpr uint32_t AFF_W = NIELS_W, ACC_W = GE_W, MIN_WAVES = 4, TB = 1024, NWIN = zkp::NWIN, NENT = zkp::NENT, DIGW = zkp::DIGW, DIG_PER_WORD = 2;
+    static constexpr bool DOUBLE_BUF = true;
     static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int16_t)(word >> (16 * (w & 1u))); }
     using Acc = ge;
     static __device__ __forceinline__ Acc identity() { return ge_identity(); }

@@ -15,7 +15,7 @@ int emul_g16_witness_qap(int kind, uint64_t value, const uint64_t* set_vals, uin
     ensure_mimc_constants();
     std::vector<uint32_t> mc; for (auto& c : g_mimc_host) put_fr(mc, c);
     const uint32_t nsc = g16_nscalars(T.nv, T.m);
-    std::vector<uint32_t> z((size_t)T.nv * 8), sdig((size_t)nsc * 8), rs(16), seedw(8);
+    std::vector<uint32_t> z((size_t)T.nv * 8), sdig((size_t)nsc * G16_DIGW), rs(16), seedw(8);
     memcpy(seedw.data(), seed, 32);
     uint64_t sv[G16_MAX_SET] = {0}; for (uint32_t i = 0; i < set_len && i < G16_MAX_SET; i++) sv[i] = set_vals[i];
     G16View V{}; V.rows = 1; V.kind = (uint32_t)kind; V.n_inst = T.n_inst; V.n_wit = T.n_wit; V.nv = T.nv; V.m = T.m;
@@ -32,16 +32,17 @@ int emul_g16_witness_qap(int kind, uint64_t value, const uint64_t* set_vals, uin
     G16Lds L; L.base = lds.data(); L.m = T.m;
     g16_qap_proof(V, C, L, 0, 0, 1, NoSync());
     for (uint32_t k = 0; k < T.nv; k++) { fr x = ld_fr(z.data(), k, 0, 1); fp_to_raw(z_raw + 8 * k, x); }
-    // digits -> canonical value (sum d_j 256^j), as 8 words via a small signed accumulate
+    // digits -> canonical value (sum d_j 1024^j), as 8 words
     auto undigit = [&](uint32_t idx, uint32_t* outw) {
-        int64_t carry = 0; uint8_t bytes[33] = {0};
-        for (int j = 0; j < 32; j++) {
-            const int32_t d = (int32_t)(int8_t)(sdig[(size_t)idx * 8 + (j >> 2)] >> (8 * (j & 3)));
-            int64_t v = d + carry; carry = 0;
-            if (v < 0) { v += 256; carry = -1; }
-            bytes[j] = (uint8_t)v;
+        unsigned __int128 lo = 0, hi = 0;     // 260-bit accumulator as two halves: value = hi * 2^128 + lo (two's complement overall)
+        // Horner from the top digit: acc = acc * 1024 + d
+        for (int j = (int)G16_NWIN - 1; j >= 0; j--) {
+            const int32_t d = (int32_t)(int16_t)(sdig[(size_t)idx * G16_DIGW + (j >> 1)] >> (16 * (j & 1)));
+            hi = (hi << 10) | (lo >> 118); lo <<= 10;
+            if (d >= 0) { const unsigned __int128 t = lo + (unsigned)d; if (t < lo) hi++; lo = t; }
+            else { const unsigned __int128 t = lo - (unsigned)(-d); if (t > lo) hi--; lo = t; }
         }
-        memcpy(outw, bytes, 32);
+        for (int k = 0; k < 4; k++) { outw[k] = (uint32_t)(lo >> (32 * k)); outw[4 + k] = (uint32_t)(hi >> (32 * k)); }
     };
     for (uint32_t i = 0; i + 1 < T.m; i++) undigit(g16_sc_h(V) + i, h_raw + 8 * i);
     memcpy(rs_raw, rs.data(), 64);
