@@ -119,8 +119,10 @@ hipError_t g16_launch_qap(const G16View& V, const G16Circuit& C, hipStream_t st)
     k_g16_qap<<<V.rows, TB, lds, st>>>(V, C);
     return hipSuccess;
 }
-void g16_launch_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* sum_g2, uint32_t* tmp_g1, hipStream_t st) {
+void g16_launch_cparts(const G16View& V, const uint32_t* sum_g1, uint32_t* tmp_g1, hipStream_t st) {
     k_g16_cparts<<<dim3((V.rows + TW - 1) / TW, 2), TW, 0, st>>>(V, sum_g1, tmp_g1);
+}
+void g16_launch_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* sum_g2, const uint32_t* tmp_g1, hipStream_t st) {
     k_g16_final<<<dim3((V.rows + TW - 1) / TW, 3), TW, 0, st>>>(V, sum_g1, sum_g2, tmp_g1);
 }
 void g16_launch_mimc(const uint64_t* values, uint32_t n, const uint32_t* mimc_c, uint8_t* out, hipStream_t st) { k_mimc_commit<<<(n + TW - 1) / TW, TW, 0, st>>>(values, n, mimc_c, out); }

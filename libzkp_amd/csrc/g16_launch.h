@@ -8,7 +8,8 @@
 void g16_launch_witness(const zkp::G16View& V, hipStream_t st);
 void g16_launch_zdigits(const zkp::G16View& V, hipStream_t st);
 hipError_t g16_launch_qap(const zkp::G16View& V, const zkp::G16Circuit& C, hipStream_t st);
-void g16_launch_final(const zkp::G16View& V, const uint32_t* sum_g1, const uint32_t* sum_g2, uint32_t* tmp_g1, hipStream_t st);
+void g16_launch_cparts(const zkp::G16View& V, const uint32_t* sum_g1, uint32_t* tmp_g1, hipStream_t st);
+void g16_launch_final(const zkp::G16View& V, const uint32_t* sum_g1, const uint32_t* sum_g2, const uint32_t* tmp_g1, hipStream_t st);
 void g16_launch_mimc(const uint64_t* values, uint32_t n, const uint32_t* mimc_c, uint8_t* out, hipStream_t st);
 void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uint32_t* table, hipStream_t st);
 void g16_launch_msm(bool g2, const zkp::MsmView& m, hipStream_t st);

@@ -519,6 +519,8 @@ void zkp_hip_shutdown(void) {
     if (!g.ready) return;
     (void)hipSetDevice(g.device);
     (void)hipDeviceSynchronize();
+    g16_release_all();
+    if (g_stark_const) { (void)hipFree(g_stark_const); g_stark_const = nullptr; }
     for (auto& sb : g.sub) { (void)hipFree(sb.ws); (void)hipStreamDestroy(sb.stream); (void)hipEventDestroy(sb.done); }
     (void)hipFree(g.d_table);
     free_set(g.p1); free_set(g.p2); free_set(g.ct);
