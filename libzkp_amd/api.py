@@ -416,29 +416,45 @@ def process_batch(batch_id, seeds=None):
     for op in ops:
         if op[0] == "membership" and len(op[2]) > MAX_SET_SIZE:      # set_membership.rs:14 (validate_set_size at prove time)
             raise ValueError("set size %d exceeds maximum allowed size %d" % (len(op[2]), MAX_SET_SIZE))
-    # bucket by variant (one batched device call each), then restore insertion order (batch.rs:123-131 is order-preserving)
+    return prove_ops(ops, seeds)
+
+
+KINDS = ("range", "threshold", "consistency", "equality", "membership", "improvement")
+
+
+def prove_kind(kind, sel, seeds=None):
+    """One batched device call for ops of one variant (tuples as stored by batch_add_*)."""
+    if kind == "range":
+        return prove_range_batch([o[1] for o in sel], [o[2] for o in sel], [o[3] for o in sel], seeds=seeds)
+    if kind == "threshold":
+        return prove_threshold_batch([o[1] for o in sel], [o[2] for o in sel], seeds=seeds)
+    if kind == "consistency":
+        return prove_consistency_batch([o[1] for o in sel], seeds=seeds)
+    if kind == "equality":
+        return prove_equality_batch([o[1] for o in sel], [o[2] for o in sel], seeds=seeds)
+    if kind == "membership":
+        return prove_membership_batch([o[1] for o in sel], [list(o[2]) for o in sel], seeds=seeds)
+    if kind == "improvement":
+        return prove_improvement_batch([o[1] for o in sel], [o[2] for o in sel])
+    raise ValueError("unsupported proof type: %s" % kind)
+
+
+def prove_ops(ops, seeds=None, prover=prove_kind, select=None):
+    """Bucket by variant (one batched device call each), then restore insertion order (batch.rs:123-131 is
+    order-preserving).  `select(kind, idx)` may narrow each bucket to the indices this process should prove
+    (multi-GPU sharding); unproved ops stay None."""
     seeds = None if seeds is None else bytes(seeds)
     if seeds is not None and len(seeds) != 32 * len(ops):
         raise ValueError("seeds must hold 32 bytes per op")
     out = [None] * len(ops)
-    for kind in ("range", "threshold", "consistency", "equality", "membership", "improvement"):
+    for kind in KINDS:
         idx = [i for i, o in enumerate(ops) if o[0] == kind]
+        if select is not None:
+            idx = select(kind, idx)
         if not idx:
             continue
         sd = None if seeds is None else b"".join(seeds[32 * i: 32 * i + 32] for i in idx)
-        sel = [ops[i] for i in idx]
-        if kind == "range":
-            proofs = prove_range_batch([o[1] for o in sel], [o[2] for o in sel], [o[3] for o in sel], seeds=sd)
-        elif kind == "threshold":
-            proofs = prove_threshold_batch([o[1] for o in sel], [o[2] for o in sel], seeds=sd)
-        elif kind == "consistency":
-            proofs = prove_consistency_batch([o[1] for o in sel], seeds=sd)
-        elif kind == "equality":
-            proofs = prove_equality_batch([o[1] for o in sel], [o[2] for o in sel], seeds=sd)
-        elif kind == "membership":
-            proofs = prove_membership_batch([o[1] for o in sel], [list(o[2]) for o in sel], seeds=sd)
-        else:
-            proofs = prove_improvement_batch([o[1] for o in sel], [o[2] for o in sel])
+        proofs = prover(kind, [ops[i] for i in idx], sd)
         for i, p in zip(idx, proofs):
             out[i] = p
     return out
