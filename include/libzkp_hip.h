@@ -97,6 +97,15 @@ int zkp_hip_snark_commit_value_batch(uint64_t n, const uint64_t* values, uint8_t
 int zkp_hip_prove_equality_batch(uint64_t n, const uint64_t* val1, const uint64_t* val2, const uint8_t* seeds,
                                  uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status);
 
+/* Replaces a loop of proof::range_proof::verify_range(proof, min, max) (range_proof.rs:28-47 ->
+ * BulletproofsBackend::verify_range_with_bounds, bulletproofs.rs:181-295).  proofs = n envelopes at `stride` bytes,
+ * lens[i] bytes used.  ok[i] = 1 accepted, 0 rejected (malformed framing, wrong bounds, invalid points/scalars, failed
+ * verification equation), 2 = well-formed proof for n_bits != 64, which this backend does not verify (the reference's
+ * prove_range always uses 64 bits, range_proof.rs:10-12).  The two verification equations of RangeProof::verify_single
+ * are folded with a transcript-derived weight (as upstream does with a random one). */
+int zkp_hip_verify_range_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, const uint32_t* lens,
+                               const uint64_t* mins, const uint64_t* maxs, uint8_t* ok);
+
 /* Replaces a loop of proof::improvement_proof::prove_improvement(old, new) (improvement_proof.rs:10-35 ->
  * StarkBackend::prove / prove_improvement, stark.rs:151-186,216-235; commitment utils/commitment.rs:38-50).
  * Deterministic (no randomness tape).  Envelope (scheme 5) = 10 + 16 + stark + 32 bytes, where the STARK proof's length

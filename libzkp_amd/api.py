@@ -338,6 +338,36 @@ def prove_membership(value, set):  # noqa: A002
     return prove_membership_batch([value], [list(set)])[0]
 
 
+def verify_range_batch(proofs, mins, maxs):
+    """Batched verify_range (range_proof.rs:28-47): list of bools.  Never raises on malformed proofs (they are False)."""
+    n = len(proofs)
+    if len(mins) != n or len(maxs) != n:
+        raise ValueError("proofs, mins, maxs must have equal length")
+    if n == 0:
+        return []
+    mn = np.array([_check_u64("min", x) for x in mins], dtype=np.uint64)
+    mx = np.array([_check_u64("max", x) for x in maxs], dtype=np.uint64)
+    blobs = [bytes(p) for p in proofs]
+    stride = max(16, max(len(b) for b in blobs))
+    if stride > 4096:                                   # a range envelope is 1478 bytes: anything this long is rejected outright
+        stride = 4096
+    buf = np.zeros((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint32)
+    for i, b in enumerate(blobs):
+        lens[i] = len(b)                                # lengths beyond the stride are rejected by the library
+        buf[i, : min(len(b), stride)] = np.frombuffer(b[:stride], dtype=np.uint8)
+    ok = np.zeros(n, dtype=np.uint8)
+    rc = _native.lib().zkp_hip_verify_range_batch(n, _P(buf), stride, _P(lens), _P(mn), _P(mx), _P(ok))
+    _native.check(rc, "zkp_hip_verify_range_batch")
+    if (ok == 2).any():
+        raise ZkpBackendError("Backend error: range proofs with n_bits != 64 are not verified by the HIP backend")
+    return [bool(x) for x in ok]
+
+
+def verify_range(proof, min, max):  # noqa: A002
+    return verify_range_batch([proof], [min], [max])[0]
+
+
 def prove_range(value, min, max):  # noqa: A002  (reference argument names)
     value, mn, mx = _check_u64("value", value), _check_u64("min", min), _check_u64("max", max)
     validate_range_params(value, mn, mx)

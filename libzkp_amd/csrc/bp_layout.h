@@ -159,6 +159,13 @@ inline std::vector<SlotList> targets_round(uint32_t r) {
     return {l, rr};
 }
 inline std::vector<SlotList> targets_ctask() { return {SlotList{{BASE_B, NWIN_U64}, {BASE_BB, NWIN}}}; }
+// range-proof verification: one target over all 130 generators (slot index == generator index == digit row)
+inline std::vector<SlotList> targets_verify() {
+    SlotList t = {{BASE_B, NWIN}, {BASE_BB, NWIN}};
+    for (uint32_t i = 0; i < BP_N; i++) t.push_back({(uint16_t)(BASE_G + i), NWIN});
+    for (uint32_t i = 0; i < BP_N; i++) t.push_back({(uint16_t)(BASE_H + i), NWIN});
+    return {t};
+}
 inline MsmLayout layout_phase1(uint32_t budget) { return make_layout(targets_phase1(), budget); }
 inline MsmLayout layout_phase2(uint32_t budget) { return make_layout(targets_phase2(), budget); }
 inline MsmLayout layout_round(uint32_t r, uint32_t budget) { return make_layout(targets_round(r), budget); }

@@ -1,0 +1,271 @@
+// Batched verification of libzkp range proofs: proof::range_proof::verify_range
+// (/root/reference/src/proof/range_proof.rs:28-47) -> BulletproofsBackend::verify_range_with_bounds
+// (/root/reference/src/backend/bulletproofs.rs:181-295) -> two `RangeProof::verify_single` (crate bulletproofs ^5.0).
+// Per-thread steps shared by the kernels (bpv_kernels.hip) and the host emulation used by the no-GPU tests.
+//
+// One envelope = two jobs (value-min under "libzkp_range_min", max-value under "libzkp_range_max").  Per job the two
+// verification equations of verify_single are folded into ONE multiscalar check with a transcript-derived weight c
+// (upstream does the same with a random c):
+//     A + x S - e_bl B~ + w (t_x - a b) B + sum u_j^2 L_j + u_j^-2 R_j + sum -(z + a s_i) G_i
+//       + sum (z + y^-i (z^2 2^i - b s_{63-i})) H_i  +  c [ (t_x - delta) B + t_xb B~ - z^2 V - x T_1 - x^2 T_2 ]  ==  0
+// The 130 generator terms go through the fixed-base MSM kernel of the prover (same tables); the 17 proof points are
+// multiplied one lane each (signed radix-4, two doublings per digit) and land in extra chunk slots of the same partial
+// array, so the prover's partial-sum and encode kernels finish the job: the sum is the identity iff its ristretto
+// encoding is 32 zero bytes.
+#pragma once
+#include "bp_steps.h"
+
+namespace zkp {
+
+enum { VP_V = 0, VP_A, VP_S, VP_T1, VP_T2, VP_L = 5, VP_R = 11, VP_NUM = 17 };
+enum { VS_Z = 0, VS_ZZ, VS_YINV, VS_A, VS_B, VS_U = 5, VS_UINV = 11, VS_NUM = 17 };
+constexpr int32_t VFY_UNSUPPORTED = 2;      // n_bits other than 64 (the reference's prove_range always uses 64, range_proof.rs:10-12)
+
+struct VfyView {
+    uint32_t M;                   // jobs
+    const uint8_t* in;            // the envelopes
+    uint64_t* proof_off;          // [M] byte offset of the job's 672-byte RangeProof
+    uint64_t* venc_off;           // [M] byte offset of the job's 32-byte value commitment encoding
+    uint8_t* kind;                // [M] transcript label
+    int32_t* bad;                 // [M] nonzero: reject (1) / unsupported (2)
+    uint32_t* pts;                // [17][40][M] decoded proof points
+    uint32_t* scal;               // [VS_NUM][8][M] Montgomery-form scalars shared between steps
+    uint32_t* digits;             // [130][DIGW][M] fixed-base digits (zero-initialised: rejected jobs contribute nothing)
+    uint32_t* vscal;              // [17][8][M] raw scalars of the proof points
+    uint32_t* partial;            // the MSM partial array; proof-point products go to chunks var_chunk0 + p
+    uint32_t var_chunk0;
+    const uint32_t* table;        // generator tables (parse step: min*B, max*B)
+};
+
+ZKP_HD inline void ld_bytes_words(uint32_t* w, const uint8_t* p, uint32_t nwords) {
+    for (uint32_t i = 0; i < nwords; i++) w[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+}
+ZKP_HD inline uint32_t ld_u32(const uint8_t* p) { uint32_t w; ld_bytes_words(&w, p, 1); return w; }
+ZKP_HD inline uint64_t ld_u64(const uint8_t* p) { return (uint64_t)ld_u32(p) | ((uint64_t)ld_u32(p + 4) << 32); }
+
+// RFC 9496 4.3.1: false for non-canonical, negative or off-curve encodings
+ZKP_HD inline bool ge_ristretto_decode(ge& p, const uint32_t w[8]) {
+    const fe s = fe_fromwords(w);
+    uint32_t chk[8]; fe_towords(chk, s);
+    bool canonical = (w[7] >> 31) == 0;
+    for (int k = 0; k < 8; k++) canonical = canonical && chk[k] == w[k];
+    const fe ss = fe_sq(s);
+    const fe u1 = fe_carry(fe_sub(fe_one(), ss)), u2 = fe_carry(fe_add(fe_one(), ss));
+    const fe u2s = fe_sq(u2);
+    const fe v = fe_carry(fe_sub(fe_carry(fe_neg(fe_mul(fe_sq(u1), fe_const_d()))), u2s));
+    fe invsqrt;
+    const bool was_square = fe_sqrt_ratio_m1(invsqrt, fe_one(), fe_mul(v, u2s));
+    const fe den_x = fe_mul(invsqrt, u2);
+    const fe den_y = fe_mul(fe_mul(invsqrt, den_x), v);
+    const fe t = fe_mul(s, den_x);
+    p.X = fe_abs(fe_carry(fe_add(t, t)));
+    p.Y = fe_mul(u1, den_y);
+    p.Z = fe_one();
+    p.T = fe_mul(p.X, p.Y);
+    return canonical && (w[0] & 1u) == 0 && was_square && !fe_isneg(p.T) && !fe_iszero(p.Y);
+}
+ZKP_HD inline bool words_are_zero(const uint32_t w[8]) { uint32_t o = 0; for (int k = 0; k < 8; k++) o |= w[k]; return o == 0; }
+// Scalar::from_canonical_bytes: raw < l
+ZKP_HD inline bool sc_raw_is_canonical(const sc& raw) {
+    const uint32_t L[8] = {0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0u, 0u, 0u, 0x10000000u};
+    for (int i = 7; i >= 0; i--) { if (raw.v[i] < L[i]) return true; if (raw.v[i] > L[i]) return false; }
+    return false;
+}
+// k * P for a raw scalar (< 2^253), signed radix-4 digits {-1, 0, 1, 2}, MSB first: 2 doublings + at most 1 addition per digit
+ZKP_HD inline ge ge_scalarmult_raw(const ge& P, const sc& k) {
+    const ge P2 = ge_dbl(P);
+    // recode into 127 digits (2 bits each) with carry: 3 -> -1 carry 1
+    uint32_t dig[8];                                   // 16 two-bit fields per word: 0, 1, 2, or 3 meaning -1
+    uint32_t carry = 0;
+    for (int w = 0; w < 8; w++) {
+        uint32_t out = 0;
+        for (int j = 0; j < 16; j++) {
+            uint32_t d = ((k.v[w] >> (2 * j)) & 3u) + carry;      // 0..4
+            carry = d >= 3u ? 1u : 0u;                           // 3 -> -1, 4 -> 0, both with carry
+            out |= (d & 3u) << (2 * j);
+        }
+        dig[w] = out;
+    }
+    // k < 2^253: the top digits (bits 254..255) are zero and absorb the last carry
+    ge acc = ge_identity();
+    for (int i = 127; i >= 0; i--) {
+        acc = ge_dbl(ge_dbl(acc));
+        const uint32_t d = (dig[i >> 4] >> (2 * (i & 15))) & 3u;
+        if (d != 0) {
+            ge q = d == 2 ? P2 : P;
+            if (d == 3) q = ge_neg(P);
+            acc = ge_add(acc, q);
+        }
+    }
+    return acc;
+}
+
+// ---- step 0: envelope framing (bulletproofs.rs:181-295 through proof_helpers.rs:12-36).  thread = envelope
+ZKP_HD inline void step_vparse(const VfyView& V, uint32_t i, const uint8_t* env, uint64_t env_off, uint32_t len, uint64_t mn, uint64_t mx) {
+    const uint32_t j0 = 2 * i, j1 = 2 * i + 1;
+    V.kind[j0] = KIND_RANGE_MIN; V.kind[j1] = KIND_RANGE_MAX;
+    V.proof_off[j0] = V.proof_off[j1] = 0; V.venc_off[j0] = V.venc_off[j1] = 0;
+    V.bad[j0] = V.bad[j1] = 1;
+    if (mn > mx || len < 10 || len > 1024u * 1024u || env[0] != 2 || env[1] != 1) return;
+    const uint32_t bl = ld_u32(env + 2), cl = ld_u32(env + 6);
+    if (bl > 900u * 1024u || cl != 32 || (uint64_t)10 + bl + cl != len) return;
+    const uint8_t* body = env + 10; const uint8_t* comm = env + 10 + bl;
+    uint32_t w[8];
+    ge vc; ld_bytes_words(w, comm, 8); if (!ge_ristretto_decode(vc, w)) return;
+    if (bl < 20 || ld_u64(body) != mn || ld_u64(body + 8) != mx) return;
+    const uint32_t n_bits = ld_u32(body + 16);
+    uint32_t pos = 20, rl[2], rp[2];
+    for (int k = 0; k < 2; k++) {
+        if (bl - pos < 4) return;
+        rl[k] = ld_u32(body + pos); pos += 4;
+        if (bl - pos < rl[k]) return;
+        rp[k] = pos; pos += rl[k];
+    }
+    if (bl - pos < 64) return;
+    ge cm, cx; uint32_t wm[8], wx[8];
+    ld_bytes_words(wm, body + pos, 8); ld_bytes_words(wx, body + pos + 32, 8);
+    if (!ge_ristretto_decode(cm, wm) || !ge_ristretto_decode(cx, wx)) return;
+    if (!(n_bits == 8 || n_bits == 16 || n_bits == 32 || n_bits == 64)) return;
+    // commitments of the two sub-proofs must be C - min*B and max*B - C
+    ge mb = ge_identity(), xb = ge_identity();
+    uint32_t dmn[DIGW], dmx[DIGW];
+    sc_recode_signed1024(dmn, sc_words((uint32_t)mn, (uint32_t)(mn >> 32), 0, 0, 0, 0, 0, 0));
+    sc_recode_signed1024(dmx, sc_words((uint32_t)mx, (uint32_t)(mx >> 32), 0, 0, 0, 0, 0, 0));
+    for (uint32_t win = 0; win < NWIN_U64; win++) {
+        const uint32_t* sub = V.table + ((size_t)BASE_B * NWIN + win) * SUBTAB_W;
+        const int32_t a = (int32_t)(int16_t)(dmn[win >> 1] >> (16 * (win & 1))), b = (int32_t)(int16_t)(dmx[win >> 1] >> (16 * (win & 1)));
+        if (a != 0) mb = msm_accumulate_digit(mb, a, sub);
+        if (b != 0) xb = msm_accumulate_digit(xb, b, sub);
+    }
+    uint32_t e1[8], e2[8];
+    ge_ristretto_encode(e1, ge_add(vc, ge_neg(mb)));
+    ge_ristretto_encode(e2, ge_add(xb, ge_neg(vc)));
+    for (int k = 0; k < 8; k++) if (e1[k] != wm[k] || e2[k] != wx[k]) return;
+    if (n_bits != 64) { V.bad[j0] = V.bad[j1] = VFY_UNSUPPORTED; return; }
+    if (rl[0] != RP_BYTES || rl[1] != RP_BYTES) return;
+    V.proof_off[j0] = env_off + 10 + rp[0]; V.proof_off[j1] = env_off + 10 + rp[1];
+    V.venc_off[j0] = env_off + 10 + pos; V.venc_off[j1] = env_off + 10 + pos + 32;
+    V.bad[j0] = V.bad[j1] = 0;
+}
+
+// ---- step 1: decode the 17 points of a job.  thread = (p, job)
+ZKP_HD inline void step_vdecode(const VfyView& V, uint32_t p, uint32_t job) {
+    if (V.bad[job]) return;
+    const uint8_t* pr = V.in + V.proof_off[job];
+    const uint8_t* src = p == VP_V ? V.in + V.venc_off[job] : p < VP_L ? pr + 32 * (p - VP_A) : p < VP_R ? pr + 224 + 64 * (p - VP_L) : pr + 224 + 64 * (p - VP_R) + 32;
+    uint32_t w[8]; ld_bytes_words(w, src, 8);
+    ge pt;
+    const bool ok = ge_ristretto_decode(pt, w);
+    if (!ok || (p != VP_V && words_are_zero(w))) { V.bad[job] = 1; return; }     // A, S, T1, T2, L_j, R_j must not be the identity
+    st_ge(V.pts, p, job, V.M, pt);
+}
+
+// ---- step 2: transcript replay, job-level scalars.  thread = job
+ZKP_HD inline void step_vtranscript(const VfyView& V, uint32_t job, Strobe& s) {
+    if (V.bad[job]) return;
+    const uint32_t M = V.M;
+    const uint8_t* pr = V.in + V.proof_off[job];
+    sc r_tx, r_txb, r_eb, r_a, r_b;
+    ld_bytes_words(r_tx.v, pr + 128, 8); ld_bytes_words(r_txb.v, pr + 160, 8); ld_bytes_words(r_eb.v, pr + 192, 8);
+    ld_bytes_words(r_a.v, pr + 608, 8); ld_bytes_words(r_b.v, pr + 640, 8);
+    if (!sc_raw_is_canonical(r_tx) || !sc_raw_is_canonical(r_txb) || !sc_raw_is_canonical(r_eb) || !sc_raw_is_canonical(r_a) || !sc_raw_is_canonical(r_b)) { V.bad[job] = 1; return; }
+    if (V.kind[job] == KIND_RANGE_MIN) merlin_init(s, "libzkp_range_min", 16); else merlin_init(s, "libzkp_range_max", 16);
+    merlin_append_bytes(s, "dom-sep", 7, "rangeproof v1", 13);
+    merlin_append_u64(s, "n", 1, BP_N);
+    merlin_append_u64(s, "m", 1, 1);
+    uint32_t w[8];
+    ld_bytes_words(w, V.in + V.venc_off[job], 8); merlin_append_words(s, "V", 1, w, 8);
+    ld_bytes_words(w, pr, 8); merlin_append_words(s, "A", 1, w, 8);
+    ld_bytes_words(w, pr + 32, 8); merlin_append_words(s, "S", 1, w, 8);
+    const sc y = merlin_challenge_scalar(s, "y", 1);
+    const sc z = merlin_challenge_scalar(s, "z", 1);
+    ld_bytes_words(w, pr + 64, 8); merlin_append_words(s, "T_1", 3, w, 8);
+    ld_bytes_words(w, pr + 96, 8); merlin_append_words(s, "T_2", 3, w, 8);
+    const sc x = merlin_challenge_scalar(s, "x", 1);
+    merlin_append_scalar(s, "t_x", 3, r_tx);
+    merlin_append_scalar(s, "t_x_blinding", 12, r_txb);
+    merlin_append_scalar(s, "e_blinding", 10, r_eb);
+    const sc wch = merlin_challenge_scalar(s, "w", 1);
+    merlin_append_bytes(s, "dom-sep", 7, "ipp v1", 6);
+    merlin_append_u64(s, "n", 1, BP_N);
+    sc u[6];
+    for (uint32_t j = 0; j < 6; j++) {
+        ld_bytes_words(w, pr + 224 + 64 * j, 8); merlin_append_words(s, "L", 1, w, 8);
+        ld_bytes_words(w, pr + 224 + 64 * j + 32, 8); merlin_append_words(s, "R", 1, w, 8);
+        u[j] = merlin_challenge_scalar(s, "u", 1);
+    }
+    const sc c = merlin_challenge_scalar(s, "libzkp-amd batch weight", 23);   // folds the two equations; not part of the proof
+    // one inversion for y, u_0..u_5 (Montgomery's trick)
+    sc pre[7]; sc run = y;
+    pre[0] = sc_one();
+    for (uint32_t j = 0; j < 6; j++) { pre[j + 1] = run; run = sc_mul(run, u[j]); }
+    sc inv = sc_invert(run);
+    sc uinv[6];
+    for (int j = 5; j >= 0; j--) { uinv[j] = sc_mul(inv, pre[j + 1]); inv = sc_mul(inv, u[j]); }
+    const sc yinv = inv;
+    const sc t_x = sc_from_raw256(r_tx), t_xb = sc_from_raw256(r_txb), e_bl = sc_from_raw256(r_eb), a = sc_from_raw256(r_a), b = sc_from_raw256(r_b);
+    const sc zz = sc_mul(z, z), xx = sc_mul(x, x);
+    sc sum_y = sc_zero(), yp = sc_one();
+    for (uint32_t i = 0; i < BP_N; i++) { sum_y = sc_add(sum_y, yp); yp = sc_mul(yp, y); }
+    const sc delta = sc_sub(sc_mul(sc_sub(z, zz), sum_y), sc_mul(sc_mul(zz, z), sc_from_u64(~0ull)));
+    st_sc(V.scal, VS_Z, job, M, z); st_sc(V.scal, VS_ZZ, job, M, zz); st_sc(V.scal, VS_YINV, job, M, yinv);
+    st_sc(V.scal, VS_A, job, M, a); st_sc(V.scal, VS_B, job, M, b);
+    for (uint32_t j = 0; j < 6; j++) { st_sc(V.scal, VS_U + j, job, M, u[j]); st_sc(V.scal, VS_UINV + j, job, M, uinv[j]); }
+    // generator coefficients of B and B~
+    st_digits(V.digits, BASE_B, job, M, sc_add(sc_mul(wch, sc_sub(t_x, sc_mul(a, b))), sc_mul(c, sc_sub(t_x, delta))));
+    st_digits(V.digits, BASE_BB, job, M, sc_sub(sc_mul(c, t_xb), e_bl));
+    // proof-point scalars
+    const sc cz = sc_mul(c, zz);
+    st_sc(V.vscal, VP_V, job, M, sc_to_raw(sc_neg(cz)));
+    st_sc(V.vscal, VP_A, job, M, sc_raw_one());
+    st_sc(V.vscal, VP_S, job, M, sc_to_raw(x));
+    st_sc(V.vscal, VP_T1, job, M, sc_to_raw(sc_neg(sc_mul(c, x))));
+    st_sc(V.vscal, VP_T2, job, M, sc_to_raw(sc_neg(sc_mul(c, xx))));
+    for (uint32_t j = 0; j < 6; j++) {
+        st_sc(V.vscal, VP_L + j, job, M, sc_to_raw(sc_mul(u[j], u[j])));
+        st_sc(V.vscal, VP_R + j, job, M, sc_to_raw(sc_mul(uinv[j], uinv[j])));
+    }
+}
+
+// ---- step 3: coefficients of G_i and H_i.  thread = (i, job)
+ZKP_HD inline void step_vscalars(const VfyView& V, uint32_t i, uint32_t job) {
+    if (V.bad[job]) return;
+    const uint32_t M = V.M;
+    sc s_i = sc_one(), s_r = sc_one();                 // s_i and s_{63-i}
+    for (uint32_t j = 0; j < 6; j++) {
+        const sc u = ld_sc(V.scal, VS_U + j, job, M), ui = ld_sc(V.scal, VS_UINV + j, job, M);
+        const bool bit = (i >> (5 - j)) & 1u;
+        s_i = sc_mul(s_i, bit ? u : ui);
+        s_r = sc_mul(s_r, bit ? ui : u);
+    }
+    const sc z = ld_sc(V.scal, VS_Z, job, M), zz = ld_sc(V.scal, VS_ZZ, job, M), a = ld_sc(V.scal, VS_A, job, M), b = ld_sc(V.scal, VS_B, job, M);
+    sc yip = sc_one(), base = ld_sc(V.scal, VS_YINV, job, M);          // y^-i by square and multiply over the 6 bits of i
+    for (uint32_t k = 0; k < 6; k++) { if ((i >> k) & 1u) yip = sc_mul(yip, base); base = sc_mul(base, base); }
+    st_digits(V.digits, BASE_G + i, job, M, sc_neg(sc_add(z, sc_mul(a, s_i))));
+    const sc h = sc_add(z, sc_mul(yip, sc_sub(sc_mul(zz, sc_from_u64(1ull << i)), sc_mul(b, s_r))));
+    st_digits(V.digits, BASE_H + i, job, M, h);
+}
+
+// ---- step 4: scalar * proof point.  thread = (p, job)
+ZKP_HD inline void step_vvarbase(const VfyView& V, uint32_t p, uint32_t job) {
+    const uint32_t M = V.M;
+    ge r = ge_identity();
+    if (!V.bad[job]) {
+        const ge pt = ld_ge(V.pts, p, job, M);
+        r = p == VP_A ? pt : ge_scalarmult_raw(pt, ld_sc(V.vscal, p, job, M));
+    }
+    st_ge(V.partial, V.var_chunk0 + p, job, M, r);
+}
+
+// ---- step 5: verdict.  thread = envelope; enc = [1][8][M] encodings of the per-job sums
+ZKP_HD inline void step_vfinal(const VfyView& V, const uint32_t* enc, uint32_t i, uint8_t* ok) {
+    uint32_t verdict = 1;
+    for (uint32_t j = 2 * i; j < 2 * i + 2; j++) {
+        if (V.bad[j] == VFY_UNSUPPORTED) { verdict = VFY_UNSUPPORTED; break; }
+        uint32_t o = 0; for (int k = 0; k < 8; k++) o |= enc[(size_t)k * V.M + j];
+        if (V.bad[j] || o != 0) verdict = 0;
+    }
+    ok[i] = (uint8_t)verdict;
+}
+
+}  // namespace zkp

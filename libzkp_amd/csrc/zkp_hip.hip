@@ -23,6 +23,7 @@
 #include "msm_kernel.h"
 #include "g16_launch.h"
 #include "stark_launch.h"
+#include "bpv_launch.h"
 #include "../../include/libzkp_hip.h"
 
 // ================================================================================================ kernels
@@ -500,6 +501,7 @@ int fresh_seeds(std::vector<uint8_t>& buf, size_t n) {
 
 #include "g16_impl.inc"
 #include "stark_impl.inc"
+#include "bpv_impl.inc"
 
 // ================================================================================================ C ABI
 extern "C" {
@@ -520,6 +522,7 @@ void zkp_hip_shutdown(void) {
     (void)hipSetDevice(g.device);
     (void)hipDeviceSynchronize();
     g16_release_all();
+    bpv_release_all();
     if (g_stark_const) { (void)hipFree(g_stark_const); g_stark_const = nullptr; }
     for (auto& sb : g.sub) { (void)hipFree(sb.ws); (void)hipStreamDestroy(sb.stream); (void)hipEventDestroy(sb.done); }
     (void)hipFree(g.d_table);

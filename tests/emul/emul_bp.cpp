@@ -2,8 +2,10 @@
 // place of kernel launches) so the no-GPU test tier can compare them with the oracle byte for byte.
 // Not part of the product library; the product has no host proving path.
 #include "../../libzkp_amd/csrc/bp_layout.h"
+#include "../../libzkp_amd/csrc/bp_verify.h"
 #include <vector>
 #include <cstdlib>
+#include <cstring>
 using namespace zkp;
 
 static std::vector<uint32_t> g_table;
@@ -83,5 +85,40 @@ int emul_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* mn
     }
     int fail = 0; for (uint32_t op = 0; op < n; op++) fail |= status[op] != 0;
     return fail;
+}
+
+// same contract as zkp_hip_verify_range_batch (include/libzkp_hip.h); nchunks = chunk count of the fixed-base part
+int emul_verify_range_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, const uint32_t* lens, const uint64_t* mins, const uint64_t* maxs,
+                            uint8_t* ok, uint32_t nchunks) {
+    ensure_table();
+    const uint32_t M = (uint32_t)(2 * n);
+    const MsmLayout L = make_layout_even(targets_verify(), nchunks);
+    std::vector<uint64_t> poff(M), voff(M); std::vector<uint8_t> kind(M); std::vector<int32_t> bad(M);
+    std::vector<uint32_t> pts((size_t)VP_NUM * GE_W * M), scal((size_t)VS_NUM * 8 * M), dig((size_t)NBASE * DIGW * M, 0), vs((size_t)VP_NUM * 8 * M, 0);
+    std::vector<uint32_t> partial((size_t)(L.nchunks() + VP_NUM) * GE_W * M), enc((size_t)8 * M);
+    VfyView V{}; V.M = M; V.in = proofs; V.proof_off = poff.data(); V.venc_off = voff.data(); V.kind = kind.data(); V.bad = bad.data();
+    V.pts = pts.data(); V.scal = scal.data(); V.digits = dig.data(); V.vscal = vs.data(); V.partial = partial.data(); V.var_chunk0 = L.nchunks(); V.table = g_table.data();
+    for (uint32_t i = 0; i < n; i++) step_vparse(V, i, proofs + stride * i, stride * i, lens[i] <= stride ? lens[i] : 0u, mins[i], maxs[i]);
+    for (uint32_t p = 0; p < VP_NUM; p++) for (uint32_t j = 0; j < M; j++) step_vdecode(V, p, j);
+    uint32_t st[50]; Strobe s; s.base = st; s.stride = 1;
+    for (uint32_t j = 0; j < M; j++) { s.pos = 0; s.pos_begin = 0; step_vtranscript(V, j, s); }
+    for (uint32_t i = 0; i < BP_N; i++) for (uint32_t j = 0; j < M; j++) step_vscalars(V, i, j);
+    MsmView m; m.rows = M; m.nslots = L.nslots(); m.nchunks = L.nchunks(); m.table = g_table.data(); m.digits = dig.data();
+    m.slot_base = L.slot_base.data(); m.slot_scalar = nullptr; m.slot_nwin = L.slot_nwin.data(); m.chunk_begin = L.chunk_begin.data(); m.chunk_win0 = L.chunk_win0.data(); m.chunk_nwin = L.chunk_nwin.data();
+    m.partial = partial.data(); m.acc_init = nullptr;
+    for (uint32_t c = 0; c < L.nchunks(); c++) for (uint32_t j = 0; j < M; j++) msm_chunk_ref(m, c, j);
+    for (uint32_t p = 0; p < VP_NUM; p++) for (uint32_t j = 0; j < M; j++) step_vvarbase(V, p, j);
+    const uint16_t tcb[2] = {0, (uint16_t)(L.nchunks() + VP_NUM)};
+    ReduceView r; r.rows = M; r.ntargets = 1; r.partial = partial.data(); r.target_chunk_begin = tcb; r.enc = enc.data(); r.out_off = nullptr; r.out = nullptr; r.corr = nullptr;
+    for (uint32_t j = 0; j < M; j++) reduce_encode_thread(r, 0, j);
+    for (uint32_t i = 0; i < n; i++) step_vfinal(V, enc.data(), i, ok);
+    return 0;
+}
+// k * P on ristretto encodings (decode, signed radix-4 multiplication, encode); 0 if the encoding is invalid
+int emul_scalarmult(const uint32_t enc_in[8], const uint32_t k[8], uint32_t enc_out[8]) {
+    ge p; if (!ge_ristretto_decode(p, enc_in)) return 0;
+    sc kk; memcpy(kk.v, k, 32);
+    ge_ristretto_encode(enc_out, ge_scalarmult_raw(p, kk));
+    return 1;
 }
 }
