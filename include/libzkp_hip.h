@@ -125,6 +125,26 @@ int zkp_hip_prove_improvement_batch_device(uint64_t n, const uint64_t* d_old, co
 int zkp_hip_prove_membership_batch(uint64_t n, const uint64_t* values, const uint64_t* sets, const uint32_t* set_counts, const uint8_t* seeds,
                                    uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status);
 
+/* Replaces advanced::process_batch (/root/reference/src/advanced/batch.rs:110-140,262-283): a mixed list of independent
+ * operations, one batched device call per variant, proofs returned in the caller's order.  `kind` = the envelope
+ * scheme id of the operation (proof/mod.rs).  Fields by kind:
+ *   RANGE (value a, min b, max c) | EQUALITY (val1 a, val2 b) | IMPROVEMENT (old a, new b)
+ *   THRESHOLD (threshold a, `count` values at lists[list_off..]) | MEMBERSHIP (value a, set of `count` <= 64 values)
+ *   CONSISTENCY (`count` values at lists[list_off..]).
+ * seeds: 32 bytes per op (NULL = OS randomness, the reference's behaviour; ignored by IMPROVEMENT, which is deterministic).
+ * Proof i occupies out[out_off[i] .. out_off[i+1]); out_off has n+1 entries and out_off[n] is the total (also when
+ * out_cap is too small: then -3 is returned and nothing is written).  status[i] as for the per-variant calls; returns 1
+ * if any op failed (the reference fails the whole batch, batch.rs:126-130: callers should then discard the output). */
+enum { ZKP_HIP_OP_RANGE = 1, ZKP_HIP_OP_EQUALITY = 2, ZKP_HIP_OP_THRESHOLD = 3, ZKP_HIP_OP_MEMBERSHIP = 4, ZKP_HIP_OP_IMPROVEMENT = 5, ZKP_HIP_OP_CONSISTENCY = 6 };
+typedef struct zkp_hip_op {
+    uint32_t kind;
+    uint32_t count;
+    uint64_t a, b, c;
+    uint64_t list_off;
+} zkp_hip_op;
+int zkp_hip_process_batch(uint64_t n, const zkp_hip_op* ops, const uint64_t* lists, const uint8_t* seeds,
+                          uint8_t* out, uint64_t out_cap, uint64_t* out_off, int32_t* status);
+
 /* Kernel timing for the roofline line of bench.py: when enabled, every launch of the dominant kernel
  * (fixed-base MSM) is bracketed by hipEvents on its own stream. */
 void zkp_hip_profile_enable(int on);

@@ -446,7 +446,55 @@ def process_batch(batch_id, seeds=None):
     for op in ops:
         if op[0] == "membership" and len(op[2]) > MAX_SET_SIZE:      # set_membership.rs:14 (validate_set_size at prove time)
             raise ValueError("set size %d exceeds maximum allowed size %d" % (len(op[2]), MAX_SET_SIZE))
-    return prove_ops(ops, seeds)
+    return process_ops(ops, seeds)
+
+
+def process_ops(ops, seeds=None):
+    """The whole mixed batch through ONE C-ABI call (zkp_hip_process_batch, the compiled replacement of
+    advanced::process_batch); same result as prove_ops, without the per-variant Python marshalling."""
+    n = len(ops)
+    if n == 0:
+        return []
+    seeds = None if seeds is None else bytes(seeds)
+    if seeds is not None and len(seeds) != 32 * n:
+        raise ValueError("seeds must hold 32 bytes per op")
+    code = {"range": _native.OP_RANGE, "equality": _native.OP_EQUALITY, "threshold": _native.OP_THRESHOLD,
+            "membership": _native.OP_MEMBERSHIP, "improvement": _native.OP_IMPROVEMENT, "consistency": _native.OP_CONSISTENCY}
+    arr = (_native.Op * n)()
+    lists = []
+    cap = 0
+    for i, o in enumerate(ops):
+        k = o[0]
+        e = arr[i]
+        e.kind = code[k]
+        if k == "range":
+            e.a, e.b, e.c = o[1], o[2], o[3]; cap += 1478
+        elif k == "equality":
+            e.a, e.b = o[1], o[2]; cap += 298
+            _ensure_key(0)
+        elif k == "improvement":
+            e.a, e.b = o[1], o[2]; cap += 3527
+        elif k == "threshold":
+            e.a, e.count, e.list_off = o[2], len(o[1]), len(lists); lists.extend(o[1]); cap += 762
+        elif k == "membership":
+            e.a, e.count, e.list_off = o[1], len(o[2]), len(lists); lists.extend(o[2]); cap += 10 + 4 + 8 * len(o[2]) + 256 + 32
+            _ensure_key(1)
+        else:
+            e.count, e.list_off = len(o[1]), len(lists); lists.extend(o[1])
+            cap += 10 + 4 + 32 * len(o[1]) + (4 + 672 + 32) * max(len(o[1]) - 1, 0) + 32
+    la = np.array(lists if lists else [0], dtype=np.uint64)
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    st = np.zeros(n, dtype=np.int32)
+    sp = None if seeds is None else ctypes.c_char_p(seeds)
+    rc = _native.lib().zkp_hip_process_batch(n, ctypes.byref(arr), _P(la), sp, _P(out), cap, _P(off), _P(st))
+    if rc < 0:
+        raise ZkpBackendError("Backend error: %s" % _native.last_error())
+    if rc != 0:
+        i = int(np.nonzero(st)[0][0])
+        raise ZkpBackendError("Proof generation failed: operation %d (%s) failed with status %d" % (i, ops[i][0], int(st[i])))
+    raw = out.tobytes()
+    return [raw[int(off[i]): int(off[i + 1])] for i in range(n)]
 
 
 KINDS = ("range", "threshold", "consistency", "equality", "membership", "improvement")

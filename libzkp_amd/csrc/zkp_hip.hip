@@ -686,3 +686,5 @@ int zkp_hip_prove_consistency_batch(uint64_t n, const uint64_t* data, const uint
 }
 
 }  // extern "C"
+
+#include "batch_impl.inc"
