@@ -151,12 +151,12 @@ void zkp_hip_profile_enable(int on);
 /* Synchronises, then returns accumulated MSM kernel time (ms), launch count, and table-entry gathers
  * (point additions) since the last reset. */
 int zkp_hip_profile_read(double* msm_ms, uint64_t* msm_launches, uint64_t* msm_point_adds, int reset);
-/* Tunables.  window budget: windows of MSM work per workgroup (multiple of 32; 0 = chosen per launch from the batch
- * size and the number of resident workgroups).  sub-batches: independent slices of a batch run on separate HIP streams
- * so one slice's latency-bound per-proof steps can overlap another's MSM (default 1: measured slower; takes effect at the next zkp_hip_init). */
+/* Tunables (benchmarking).  window budget: 0 = chunking chosen per launch from the batch size (default); 32*T = slot-aligned
+ * chunks of 32*T windows; 10000 + c = the window-granular layout with about c chunks.  sub-batches: independent slices
+ * of a range batch on separate HIP streams (default 1: measured slower; takes effect at the next
+ * zkp_hip_init).  msm variant: values >= 100 scale the resident-workgroup count the chunk choice aims at (x100). */
 void zkp_hip_set_window_budget(uint32_t budget);
 void zkp_hip_set_subbatches(uint32_t n);
-/* MSM kernel variant (A/B benchmarking): 1 = register-staged LDS fill, 2 = LDS-DMA double buffer (default). */
 void zkp_hip_set_msm_variant(uint32_t v);
 
 #ifdef __cplusplus

@@ -84,20 +84,10 @@ template <class F> ZKP_HD inline Jac<F> jac_madd(const Jac<F>& p, const Aff<F>& 
     return r;
 }
 
-// madd-2007-bl without the exceptional-case branches, for the MSM inner loop: the accumulator starts from a fixed offset
-// point (never infinity) and meeting +-(table entry) would need a discrete-log relation between key points and the
-// offset (probability ~2^-250); H = 0 then collapses to Z3 = 0 rather than to wrong finite coordinates.
-template <class F> ZKP_HD inline Jac<F> jac_madd_nocheck(const Jac<F>& p, const Aff<F>& q) {
-    const F Z1Z1 = f_sq(p.Z);
-    const F U2 = f_mul(q.x, Z1Z1), S2 = f_mul(f_mul(q.y, p.Z), Z1Z1);
-    const F H = f_sub(U2, p.X), rr = f_dbl(f_sub(S2, p.Y));
-    const F HH = f_sq(H), I = f_dbl(f_dbl(HH)), J = f_mul(H, I), V = f_mul(p.X, I);
-    Jac<F> r;
-    r.X = f_sub(f_sub(f_sq(rr), J), f_dbl(V));
-    r.Y = f_sub(f_mul(rr, f_sub(V, r.X)), f_dbl(f_mul(p.Y, J)));
-    r.Z = f_sub(f_sub(f_sq(f_add(p.Z, H)), Z1Z1), HH);
-    return r;
-}
+// The MSM inner loops use madd-2007-bl WITHOUT the exceptional-case branches (g1_madd_lazy, g2_madd_lazy): the
+// accumulator starts from a fixed offset point (never infinity) and meeting +-(table entry) would need a discrete-log
+// relation between key points and the offset (probability ~2^-250); H = 0 then collapses to Z3 = 0 rather than to
+// wrong finite coordinates.  jac_madd above (with the branches) is the reference form the tests compare against.
 
 // The G1 MSM inner loop: madd-2007-bl on lazily reduced limbs (bounds proved in tests/test_fq_bounds.py).
 // p = (X1, Y1, Z1) safe (< 4p... in fact < 3p, carried); q affine with safe coordinates (table entries are canonical).

@@ -208,20 +208,6 @@ ZKP_HD inline sc sc_invert_fermat(const sc& a) {
     return acc;
 }
 
-// signed radix-256 recoding of a canonical raw scalar (< 2^253): 32 digits in [-128, 127], packed 4 per word
-ZKP_HD inline void sc_recode_signed256(uint32_t packed[8], const sc& raw) {
-    uint32_t carry = 0;
-    ZKP_UNROLL for (int w = 0; w < 8; w++) {
-        uint32_t out = 0;
-        ZKP_UNROLL for (int k = 0; k < 4; k++) {
-            uint32_t d = ((raw.v[w] >> (8 * k)) & 0xffu) + carry;   // 0..256
-            carry = d >= 128u ? 1u : 0u;                            // digit = d - 256*carry in [-128, 127]
-            out |= (d & 0xffu) << (8 * k);
-        }
-        packed[w] = out;
-    }
-}
-
 // signed radix-1024 recoding of a canonical raw scalar (< 2^253): 26 digits in [-511, 512], two 16-bit digits per word
 // (13 words).  Used by the Bulletproofs fixed-base tables (512 entries per window, 26 windows).
 ZKP_HD inline void sc_recode_signed1024(uint32_t packed[13], const sc& raw) {

@@ -41,9 +41,6 @@ void emul_sc_op(int op, const uint32_t a[8], const uint32_t b[8], uint32_t out[8
     r = sc_to_raw(r); memcpy(out, r.v, 32);
 }
 void emul_sc_from_wide(const uint32_t w[16], uint32_t out[8]) { sc r = sc_to_raw(sc_from_wide(w)); memcpy(out, r.v, 32); }
-void emul_sc_recode(const uint32_t a[8], int8_t digits[32]) {
-    sc x; memcpy(x.v, a, 32); uint32_t p[8]; sc_recode_signed256(p, x); memcpy(digits, p, 32);
-}
 void emul_sc_recode1024(const uint32_t a[8], int16_t digits[26]) {
     sc x; memcpy(x.v, a, 32); uint32_t p[13]; sc_recode_signed1024(p, x); memcpy(digits, p, 52);
 }

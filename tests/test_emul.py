@@ -58,9 +58,6 @@ def test_scalars(emul):
         if a and i < 12:                        # Fermat ladder cross-check
             lib.emul_sc_op(5, W(a), W(b), out)
             assert I(out) == pow(a, LL - 2, LL)
-        dg = (ctypes.c_int8 * 32)()
-        lib.emul_sc_recode(W(a), dg)
-        assert sum(int(dg[k]) << (8 * k) for k in range(32)) == a
         dg10 = (ctypes.c_int16 * 26)()
         lib.emul_sc_recode1024(W(a), dg10)
         assert sum(int(dg10[k]) << (10 * k) for k in range(26)) == a and all(-511 <= int(x) <= 512 for x in dg10)
