@@ -58,7 +58,19 @@ def cpu_baseline(sample, threads):
     rc = orc.zkp_oracle_prove_range_batch(u64(sample), P(v), P(mn), P(mx), 64, P(seeds), P(out), u64(PROOF_BYTES), P(lens), P(st), threads)
     dt = time.perf_counter() - t0
     assert rc == 0
+    # BASELINE.md B2 / configs[0]: the reference's own harness shape, benchmark_proof_generation("range", 100)
+    # (advanced/mod.rs:83-172: 100 x prove_range(50, 0, 100), one thread), next to the README's "~5 ms" figure
+    k = 100
+    v1, mn1, mx1 = np.full(k, 50, dtype=np.uint64), np.zeros(k, dtype=np.uint64), np.full(k, 100, dtype=np.uint64)
+    sd1 = make_workload(k, 7)[3]
+    out1, len1, st1 = np.zeros((k, PROOF_BYTES), dtype=np.uint8), np.zeros(k, dtype=np.uint32), np.zeros(k, dtype=np.int32)
+    t1 = time.perf_counter()
+    rc1 = orc.zkp_oracle_prove_range_batch(u64(k), P(v1), P(mn1), P(mx1), 64, P(sd1), P(out1), u64(PROOF_BYTES), P(len1), P(st1), 1)
+    dt1 = time.perf_counter() - t1
+    assert rc1 == 0
     return {"value": sample / dt, "unit": "proofs/s", "cores": threads, "kind": "port",
+            "c1_single_thread": {"workload": "100 x prove_range(50, 0, 100), 1 thread (BASELINE configs[0])", "ms_per_proof": dt1 / k * 1e3,
+                                 "proofs_per_second": k / dt1},
             "sample": "first %d ops of the same 4096-op workload, oracle/c (scalar C restatement of upstream's Straus + "
                       "generator-folding prover), OpenMP %d threads, %.1f s wall" % (sample, threads, dt)}
 
