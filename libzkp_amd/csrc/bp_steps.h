@@ -51,8 +51,8 @@ struct BpView {
     uint32_t* d1;                  // [260] packed signed digits
     uint32_t* d2;                  // [4]
     uint32_t* dr;                  // [130]
-    uint32_t* ypow;                // [64]
-    uint32_t* yinvpow;             // [64]
+    uint32_t* yinvpow;             // [64] y^-i (written by step_poly)
+    uint32_t* ypq;                 // [32]: y^b (b < 8), y^(8a) (a < 8), then the same for y^-1: y^i = y^(8a) * y^b
     uint32_t* r0;                  // [64]
     uint32_t* r1;                  // [64]
     uint32_t* pp;                  // [3*64] products
@@ -238,11 +238,14 @@ ZKP_HD inline void step_transcript1(const BpView& V, uint32_t job, Strobe& s) {
     strobe_save(V, job, s);
     st_sc(V.scal, SC_Y, job, M, y);
     st_sc(V.scal, SC_Z, job, M, z);
+    // short power tables (28 products); step_poly forms y^i = y^(8a) y^b and y^-i per (i, job) lane with one product each
     const sc yinv = sc_invert(y);
-    sc yp = sc_one(), yip = sc_one();
-    for (uint32_t i = 0; i < BP_N; i++) {
-        st_sc(V.ypow, i, job, M, yp); st_sc(V.yinvpow, i, job, M, yip);
-        yp = sc_mul(yp, y); yip = sc_mul(yip, yinv);
+    for (uint32_t h = 0; h < 2; h++) {
+        const sc base = h ? yinv : y;
+        sc p = sc_one();
+        for (uint32_t b = 0; b < 8; b++) { st_sc(V.ypq, 16 * h + b, job, M, p); p = sc_mul(p, base); }
+        sc q = sc_one();                                   // p = base^8 here
+        for (uint32_t a = 0; a < 8; a++) { st_sc(V.ypq, 16 * h + 8 + a, job, M, q); q = sc_mul(q, p); }
     }
     uint8_t* pr = V.out + V.proof_off[job];
     put_bytes(pr, Ae.v, 8); put_bytes(pr + 32, Se.v, 8);
@@ -252,7 +255,9 @@ ZKP_HD inline void step_transcript1(const BpView& V, uint32_t job, Strobe& s) {
 // polynomial coefficients.  thread = (i, job)
 ZKP_HD inline void step_poly(const BpView& V, uint32_t i, uint32_t job) {
     const uint32_t M = V.M;
-    const sc z = ld_sc(V.scal, SC_Z, job, M), yi = ld_sc(V.ypow, i, job, M);
+    const sc yi = sc_mul(ld_sc(V.ypq, 8 + (i >> 3), job, M), ld_sc(V.ypq, i & 7u, job, M));
+    st_sc(V.yinvpow, i, job, M, sc_mul(ld_sc(V.ypq, 24 + (i >> 3), job, M), ld_sc(V.ypq, 16 + (i & 7u), job, M)));
+    const sc z = ld_sc(V.scal, SC_Z, job, M);
     const sc zz = sc_mul(z, z);
     const uint32_t bit = (uint32_t)(V.v[job] >> i) & 1u;
     const sc one = sc_one();
@@ -267,19 +272,32 @@ ZKP_HD inline void step_poly(const BpView& V, uint32_t i, uint32_t job) {
     st_sc(V.pp, 64 + i, job, M, sc_mul(sc_add(l0, l1), sc_add(r0, r1)));
     st_sc(V.pp, 128 + i, job, M, sc_mul(l1, r1));
 }
-// thread = job
-ZKP_HD inline void step_poly_sum(const BpView& V, uint32_t job) {
+// t0, t1, t2 = sums over i of the three product columns.  On the GPU eight lanes per job each add every 8th entry and a
+// tree through LDS joins them (modular sums are exact, so the grouping does not change a bit); host emulation adds all
+// eight parts in one thread.
+struct ScTriple { sc a, b, c; };
+ZKP_HD inline ScTriple triple_add(const ScTriple& x, const ScTriple& y) { return ScTriple{sc_add(x.a, y.a), sc_add(x.b, y.b), sc_add(x.c, y.c)}; }
+ZKP_HD inline ScTriple step_poly_sum_part(const BpView& V, uint32_t part, uint32_t job) {
     const uint32_t M = V.M;
-    sc t0 = sc_zero(), t1 = sc_zero(), t2 = sc_zero();
-    for (uint32_t i = 0; i < BP_N; i++) {
-        t0 = sc_add(t0, ld_sc(V.pp, i, job, M));
-        t1 = sc_add(t1, ld_sc(V.pp, 64 + i, job, M));
-        t2 = sc_add(t2, ld_sc(V.pp, 128 + i, job, M));
+    ScTriple t{sc_zero(), sc_zero(), sc_zero()};
+    for (uint32_t i = part; i < BP_N; i += 8) {
+        t.a = sc_add(t.a, ld_sc(V.pp, i, job, M));
+        t.b = sc_add(t.b, ld_sc(V.pp, 64 + i, job, M));
+        t.c = sc_add(t.c, ld_sc(V.pp, 128 + i, job, M));
     }
-    t1 = sc_sub(sc_sub(t1, t0), t2);
+    return t;
+}
+ZKP_HD inline void step_poly_sum_finish(const BpView& V, uint32_t job, const ScTriple& t) {
+    const uint32_t M = V.M;
+    const sc t0 = t.a, t2 = t.c, t1 = sc_sub(sc_sub(t.b, t0), t2);
     st_sc(V.scal, SC_T0, job, M, t0); st_sc(V.scal, SC_T1, job, M, t1); st_sc(V.scal, SC_T2, job, M, t2);
     st_digits(V.d2, 0, job, M, t1);
     st_digits(V.d2, 2, job, M, t2);
+}
+ZKP_HD inline void step_poly_sum(const BpView& V, uint32_t job) {
+    ScTriple t = step_poly_sum_part(V, 0, job);
+    for (uint32_t p = 1; p < 8; p++) t = triple_add(t, step_poly_sum_part(V, p, job));
+    step_poly_sum_finish(V, job, t);
 }
 // thread = job
 ZKP_HD inline void step_transcript2(const BpView& V, uint32_t job, Strobe& s) {

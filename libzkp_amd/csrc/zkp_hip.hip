@@ -45,9 +45,31 @@ __global__ void __launch_bounds__(TB) k_poly(BpView V) {
     const uint32_t job = blockIdx.x * TB + threadIdx.x;
     if (job < V.M) step_poly(V, blockIdx.y, job);
 }
+// eight lanes per job (block = 8 jobs x 8 parts): each adds every 8th entry, a 3-level tree through LDS joins the parts
+__device__ __forceinline__ ScTriple triple_tree8(ScTriple t, uint32_t* lds) {
+    const uint32_t lane = threadIdx.x, grp = lane >> 3;
+    for (uint32_t stride = 4; stride >= 1; stride >>= 1) {
+        if (grp >= stride && grp < 2 * stride) {
+            ZKP_UNROLL for (int k = 0; k < 8; k++) { lds[k * TW + lane] = t.a.v[k]; lds[(8 + k) * TW + lane] = t.b.v[k]; lds[(16 + k) * TW + lane] = t.c.v[k]; }
+        }
+        __syncthreads();
+        if (grp < stride) {
+            ScTriple o; const uint32_t src = lane + stride * 8;
+            ZKP_UNROLL for (int k = 0; k < 8; k++) { o.a.v[k] = lds[k * TW + src]; o.b.v[k] = lds[(8 + k) * TW + src]; o.c.v[k] = lds[(16 + k) * TW + src]; }
+            t = triple_add(t, o);
+        }
+        __syncthreads();
+    }
+    return t;
+}
 __global__ void __launch_bounds__(TW) k_poly_sum(BpView V) {
-    const uint32_t job = blockIdx.x * TW + threadIdx.x;
-    if (job < V.M) step_poly_sum(V, job);
+    __shared__ uint32_t lds[24 * TW];
+    const uint32_t job = blockIdx.x * 8 + (threadIdx.x & 7u), part = threadIdx.x >> 3;
+    const bool active = job < V.M;
+    ScTriple t{sc_zero(), sc_zero(), sc_zero()};
+    if (active) t = step_poly_sum_part(V, part, job);
+    t = triple_tree8(t, lds);
+    if (active && part == 0) step_poly_sum_finish(V, job, t);
 }
 __global__ void __launch_bounds__(TB) k_lr_init(BpView V) {
     const uint32_t job = blockIdx.x * TB + threadIdx.x;
@@ -57,7 +79,7 @@ __global__ void __launch_bounds__(TB) k_round_prep(BpView V, uint32_t r) {
     const uint32_t job = blockIdx.x * TB + threadIdx.x;
     if (job < V.M) step_round_prep(V, r, blockIdx.y, job);
 }
-__global__ void __launch_bounds__(TW) k_round_sum(BpView V, uint32_t r) {
+__global__ void __launch_bounds__(TW) k_round_sum(BpView V, uint32_t r) {      // <= 64 additions per lane: the 8-lane split measured slower here
     const uint32_t job = blockIdx.x * TW + threadIdx.x;
     if (job < V.M) step_round_sum(V, r, job);
 }
@@ -312,7 +334,7 @@ size_t carve(uint8_t* base, uint32_t M, uint32_t C, uint32_t max_chunks, Ws* w) 
     t.V.kind = t.J.kind; t.V.proof_off = t.J.proof_off; t.V.commit_off = t.J.commit_off;
     t.V.tape = (uint32_t*)take(W * TAPE_SLOTS); t.V.gamma = (uint32_t*)take(W);
     t.V.d1 = (uint32_t*)take(WD * P1_NSLOTS); t.V.d2 = (uint32_t*)take(WD * P2_NSLOTS); t.V.dr = (uint32_t*)take(WD * PR_NSLOTS);
-    t.V.ypow = (uint32_t*)take(W * 64); t.V.yinvpow = (uint32_t*)take(W * 64); t.V.r0 = (uint32_t*)take(W * 64); t.V.r1 = (uint32_t*)take(W * 64);
+    t.V.yinvpow = (uint32_t*)take(W * 64); t.V.ypq = (uint32_t*)take(W * 32); t.V.r0 = (uint32_t*)take(W * 64); t.V.r1 = (uint32_t*)take(W * 64);
     t.V.pp = (uint32_t*)take(W * 192); t.V.ab = (uint32_t*)take(W * 256); t.V.gh = (uint32_t*)take(W * 128);
     t.V.scal = (uint32_t*)take(W * SC_NUM); t.V.tstate = (uint32_t*)take(4ull * 52 * M); t.V.enc = (uint32_t*)take(W * 3);
     t.partial = (uint32_t*)take((size_t)max_chunks * GE_W * 4 * M);
@@ -382,7 +404,7 @@ int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st) {
     if ((rc = msm_and_encode(g.p1, M, w.V.d1, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
     k_transcript1<<<gw, TW, 0, st>>>(w.V);
     k_poly<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V);
-    k_poly_sum<<<gw, TW, 0, st>>>(w.V);
+    k_poly_sum<<<(M + 7) / 8, TW, 0, st>>>(w.V);
     if ((rc = msm_and_encode(g.p2, M, w.V.d2, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
     k_transcript2<<<gw, TW, 0, st>>>(w.V);
     k_lr_init<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V);

@@ -48,12 +48,12 @@ int emul_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* mn
     auto words = [&](size_t k) { return std::vector<uint32_t>(k * 8 * M, 0xDEADBEEFu); };
     auto dwords = [&](size_t k) { return std::vector<uint32_t>(k * DIGW * M, 0xDEADBEEFu); };
     auto d1 = dwords(P1_NSLOTS), d2 = dwords(P2_NSLOTS), dr = dwords(PR_NSLOTS);
-    auto tape = words(TAPE_SLOTS), gamma = words(1), ypow = words(64), yinv = words(64),
+    auto tape = words(TAPE_SLOTS), gamma = words(1), yinv = words(64), ypq = words(32),
          r0 = words(64), r1 = words(64), pp = words(192), ab = words(256), gh = words(128), scal = words(SC_NUM), enc = words(3);
     std::vector<uint32_t> tstate((size_t)52 * M);
     BpView V; V.M = M; V.v = v.data(); V.seed_ix = six.data(); V.proof_ix = pix.data(); V.bl_plus = blp.data(); V.bl_minus = blm.data(); V.kind = kind.data();
     V.seeds = seedw.data(); V.proof_off = poff.data(); V.commit_off = coff.data(); V.out = out;
-    V.tape = tape.data(); V.gamma = gamma.data(); V.d1 = d1.data(); V.d2 = d2.data(); V.dr = dr.data(); V.ypow = ypow.data(); V.yinvpow = yinv.data();
+    V.tape = tape.data(); V.gamma = gamma.data(); V.d1 = d1.data(); V.d2 = d2.data(); V.dr = dr.data(); V.yinvpow = yinv.data(); V.ypq = ypq.data();
     V.r0 = r0.data(); V.r1 = r1.data(); V.pp = pp.data(); V.ab = ab.data(); V.gh = gh.data(); V.scal = scal.data(); V.tstate = tstate.data(); V.enc = enc.data();
     std::vector<uint32_t> partial;
     uint32_t st[50]; Strobe s; s.base = st; s.stride = 1;
