@@ -144,7 +144,7 @@ void g16_launch_msm(bool g2, const MsmView& m, hipStream_t st) {
     else k_msm_dma<G2Msm><<<grid, G2Msm::TB, msm_lds_bytes<G2Msm>(), st>>>(m, ngroups, nblocks);
 }
 void g16_launch_sum(bool g2, const ReduceView& R, uint32_t* sums, hipStream_t st) {
-    if (!g2) k_sum_t<G1Msm><<<dim3((R.rows + 7) / 8, R.ntargets), TW, 0, st>>>(R, sums);
-    else k_sum_t<G2Msm><<<dim3((R.rows + 7) / 8, R.ntargets), TW, 0, st>>>(R, sums);
+    if (!g2) k_sum_t<G1Msm><<<dim3((R.rows + 63) / 64, R.ntargets), SUM_TB, 0, st>>>(R, sums);
+    else k_sum_t<G2Msm><<<dim3((R.rows + 63) / 64, R.ntargets), SUM_TB, 0, st>>>(R, sums);
 }
 void g16_launch_serialize(bool g2, const uint32_t* jac, uint32_t rows, uint8_t* out, hipStream_t st) { k_g16_serialize<<<(rows + TW - 1) / TW, TW, 0, st>>>(g2, jac, rows, out); }

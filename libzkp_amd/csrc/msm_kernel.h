@@ -78,34 +78,33 @@ __global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint
 #endif
 }
 
-// 8 lanes cooperate on one (target, row): each sums every 8th chunk partial, then a 3-level tree through LDS.
+// Partial sums of one target: a block owns 64 consecutive rows, its 8 waves each add every 8th chunk partial for those
+// rows (lane = row: every load is a full 256-byte coalesced segment), then a 3-level tree through LDS joins the waves.
+static constexpr int SUM_TB = 512;
 template <class T>
-__global__ void __launch_bounds__(TW) k_sum_t(ReduceView R, uint32_t* sums) {
-    __shared__ uint32_t lds[T::ACC_W * TW];
-    const uint32_t lane = threadIdx.x, rl = lane & 7u, grp = lane >> 3;
-    const uint32_t row = blockIdx.x * 8 + rl, target = blockIdx.y;
+__global__ void __launch_bounds__(SUM_TB) k_sum_t(ReduceView R, uint32_t* sums) {
+    __shared__ uint32_t lds[T::ACC_W * 256];                       // [word][4 waves x 64 lanes]
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t row = blockIdx.x * 64 + lane, target = blockIdx.y;
     const bool active = row < R.rows;
     const uint32_t c0 = R.target_chunk_begin[target], c1 = R.target_chunk_begin[target + 1];
     typename T::Acc acc = T::identity();
     bool have = false;
     if (active) {
-        for (uint32_t c = c0 + grp; c < c1; c += 8) {
+        for (uint32_t c = c0 + wave; c < c1; c += 8) {
             const typename T::Acc p = T::load(R.partial, c, row, R.rows);
             acc = have ? T::add(acc, p) : p;
             have = true;
         }
     }
-    uint32_t* mine = lds + lane;     // word k of this lane at mine[k * TW]
     for (uint32_t stride = 4; stride >= 1; stride >>= 1) {
-        if (grp >= stride && grp < 2 * stride) T::store(lds, 0, lane, TW, acc);
+        if (wave >= stride && wave < 2 * stride) T::store(lds, 0, (wave - stride) * 64 + lane, 256, acc);
         __syncthreads();
-        if (grp < stride) acc = T::add(acc, T::load(lds, 0, lane + stride * 8, TW));
+        if (wave < stride) acc = T::add(acc, T::load(lds, 0, wave * 64 + lane, 256));
         __syncthreads();
     }
-    (void)mine;
-    if (grp == 0 && active) {
+    if (wave == 0 && active) {
         if (R.corr) acc = T::add(acc, T::load(R.corr, target, 0, 1));
         T::store(sums, target, row, R.rows, acc);
     }
 }
-

@@ -380,7 +380,7 @@ int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32
 int launch_reduce(const DevLayout& D, uint32_t rows, const uint32_t* partial, uint32_t* sums, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
     ReduceView R; R.rows = rows; R.ntargets = D.ntargets; R.partial = partial; R.target_chunk_begin = D.target_chunk_begin;
     R.enc = enc; R.out_off = out_off; R.out = out; R.corr = nullptr;
-    k_sum_t<EdMsm><<<dim3((rows + 7) / 8, D.ntargets), TW, 0, st>>>(R, sums);
+    k_sum_t<EdMsm><<<dim3((rows + 63) / 64, D.ntargets), SUM_TB, 0, st>>>(R, sums);
     k_encode<<<dim3((rows + TW - 1) / TW, D.ntargets), TW, 0, st>>>(R, sums);
     return 0;
 }
