@@ -173,6 +173,7 @@ def prove_consistency(data):
 MAX_SET_SIZE = 64
 _key_dir_override = None
 _keys_loaded = {}
+_key_blobs = {}            # kind -> proving-key bytes of the loaded key (multi-GPU: rank 0's key is broadcast, sharding.py)
 _KEY_PREFIX = {0: "equality_mimc", 1: "membership_mimc"}          # snark.rs:306,327
 _snark_lock = threading.Lock()
 
@@ -209,6 +210,7 @@ def _ensure_key(kind):
             blob = open(path, "rb").read()
             if L.zkp_hip_groth16_load_key(kind, blob, len(blob)) != 0:
                 raise ZkpBackendError("Configuration error: %s" % _native.last_error())
+            _key_blobs[kind] = blob
         else:
             # load_or_generate_setup (snark.rs:122-139): fresh trusted setup (OS randomness), persisted if a key dir is set
             pk_len, vk_len = ctypes.c_uint64(), ctypes.c_uint64()
@@ -223,8 +225,24 @@ def _ensure_key(kind):
                     open(os.path.join(d, _KEY_PREFIX[kind] + "_vk.bin"), "wb").write(vk.raw[: vk_len.value])
                 except OSError:
                     pass                                              # the reference ignores persist errors too (snark.rs:131-133)
+            _key_blobs[kind] = pk.raw[: pk_len.value]
             path = path or "<generated in memory>"
         _keys_loaded[kind] = path
+
+
+def export_proving_key(kind):
+    """The loaded (or freshly generated) proving key of a circuit (0 equality, 1 membership) in ark-serialize form."""
+    _ensure_key(kind)
+    return _key_blobs[kind]
+
+
+def install_proving_key(kind, blob):
+    """Make `blob` THE proving key of this process (every rank of a multi-GPU job must prove under one setup)."""
+    with _snark_lock:
+        if _native.lib().zkp_hip_groth16_load_key(kind, blob, len(blob)) != 0:
+            raise ZkpBackendError("Configuration error: %s" % _native.last_error())
+        _key_blobs[kind] = bytes(blob)
+        _keys_loaded[kind] = "<installed>"
 
 
 def snark_commit_value_batch(values):

@@ -51,6 +51,37 @@ def process_range_batch_sharded(values, mins, maxs, seeds, prover=None, device=N
     return out
 
 
+def share_snark_keys(kinds, device=None, export=None, install=None):
+    """One trusted setup for the whole job: rank 0 loads or generates the proving key of each circuit in
+    `kinds` (0 equality, 1 membership) and broadcasts its ark-serialized bytes; the other ranks install exactly that key.
+    Without this every rank would run its own random setup and the job's proofs would verify under different keys."""
+    import torch
+    import torch.distributed as dist
+
+    from . import api
+    export = export or api.export_proving_key
+    install = install or api.install_proving_key
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        for k in kinds:
+            export(k)
+        return
+    rank = dist.get_rank()
+    for k in sorted(set(kinds)):
+        blob = export(k) if rank == 0 else b""
+        size = torch.tensor([len(blob)], dtype=torch.int64)
+        if device is not None:
+            size = size.to(device)
+        dist.broadcast(size, src=0)
+        buf = torch.zeros(int(size.item()), dtype=torch.uint8)
+        if rank == 0:
+            buf = torch.frombuffer(bytearray(blob), dtype=torch.uint8).clone()
+        if device is not None:
+            buf = buf.to(device)
+        dist.broadcast(buf, src=0)
+        if rank != 0:
+            install(k, buf.cpu().numpy().tobytes())
+
+
 def process_ops_sharded(ops, seeds=None, prover=None, device=None):
     """Mixed batch (tuples as stored by api.batch_add_*): every rank passes the FULL op list (and 32 bytes of seed per
     op, required when world > 1 so that all ranks agree on the randomness); each variant's bucket is split into
@@ -66,6 +97,8 @@ def process_ops_sharded(ops, seeds=None, prover=None, device=None):
     rank = dist.get_rank() if dist.is_initialized() else 0
     if world > 1 and seeds is None:
         raise ValueError("sharded proving needs explicit per-op seeds")
+    if prover is api.prove_kind:
+        share_snark_keys([0] * any(o[0] == "equality" for o in ops) + [1] * any(o[0] == "membership" for o in ops), device=device)
 
     def select_for(r):
         def select(kind, idx):

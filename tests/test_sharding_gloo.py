@@ -88,6 +88,14 @@ MIXED_WORKER = textwrap.dedent("""
         if i %% 2 == 0:
             ops.append(("improvement", 10 * i, 10 * i + 7 + i))
     seeds = bytes((7 * k + 3) %% 256 for k in range(32 * len(ops)))
+    # one trusted setup per job: rank 0's key bytes reach every other rank
+    from libzkp_amd.sharding import share_snark_keys
+    installed = {}
+    share_snark_keys([0, 1], export=lambda k: b"key-of-rank-0-circuit-%%d" %% k * (1000 + k), install=lambda k, b: installed.__setitem__(k, b))
+    if int(os.environ["RANK"]) == 0:
+        assert installed == {}
+    else:
+        assert installed == {0: b"key-of-rank-0-circuit-0" * 1000, 1: b"key-of-rank-0-circuit-1" * 1001}
     got = process_ops_sharded(ops, seeds, prover=prover)
     ref = api.prove_ops(ops, seeds, prover=prover)   # unsharded, same stand-in
     assert len(got) == len(ops) and all(g == r and g is not None for g, r in zip(got, ref)), "sharded mixed batch differs"
