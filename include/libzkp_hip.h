@@ -105,6 +105,10 @@ int zkp_hip_prove_equality_batch(uint64_t n, const uint64_t* val1, const uint64_
  * are folded with a transcript-derived weight (as upstream does with a random one). */
 int zkp_hip_verify_range_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, const uint32_t* lens,
                                const uint64_t* mins, const uint64_t* maxs, uint8_t* ok);
+/* Same for proof::threshold_proof::verify_threshold(proof, threshold) (threshold_proof.rs:34-47 -> bulletproofs.rs:550-626):
+ * one RangeProof per envelope (scheme 3) whose commitment must be C - threshold*B. */
+int zkp_hip_verify_threshold_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, const uint32_t* lens,
+                                   const uint64_t* thresholds, uint8_t* ok);
 
 /* Replaces a loop of proof::improvement_proof::prove_improvement(old, new) (improvement_proof.rs:10-35 ->
  * StarkBackend::prove / prove_improvement, stark.rs:151-186,216-235; commitment utils/commitment.rs:38-50).

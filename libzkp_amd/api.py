@@ -382,6 +382,32 @@ def verify_range_batch(proofs, mins, maxs):
     return [bool(x) for x in ok]
 
 
+def verify_threshold_batch(proofs, thresholds):
+    """Batched verify_threshold (threshold_proof.rs:34-47): list of bools."""
+    n = len(proofs)
+    if len(thresholds) != n:
+        raise ValueError("proofs, thresholds must have equal length")
+    if n == 0:
+        return []
+    th = np.array([_check_u64("threshold", x) for x in thresholds], dtype=np.uint64)
+    blobs = [bytes(p) for p in proofs]
+    stride = min(4096, max(16, max(len(b) for b in blobs)))
+    buf = np.zeros((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint32)
+    for i, b in enumerate(blobs):
+        lens[i] = len(b)
+        buf[i, : min(len(b), stride)] = np.frombuffer(b[:stride], dtype=np.uint8)
+    ok = np.zeros(n, dtype=np.uint8)
+    _native.check(_native.lib().zkp_hip_verify_threshold_batch(n, _P(buf), stride, _P(lens), _P(th), _P(ok)), "zkp_hip_verify_threshold_batch")
+    if (ok == 2).any():
+        raise ZkpBackendError("Backend error: threshold proofs with n_bits != 64 are not verified by the HIP backend")
+    return [bool(x) for x in ok]
+
+
+def verify_threshold(proof, threshold):
+    return verify_threshold_batch([proof], [threshold])[0]
+
+
 def verify_range(proof, min, max):  # noqa: A002
     return verify_range_batch([proof], [min], [max])[0]
 

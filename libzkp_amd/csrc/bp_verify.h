@@ -148,6 +148,39 @@ ZKP_HD inline void step_vparse(const VfyView& V, uint32_t i, const uint8_t* env,
     V.bad[j0] = V.bad[j1] = 0;
 }
 
+// ---- step 0 for threshold proofs (threshold_proof.rs:34-47 + bulletproofs.rs:550-626): one job per envelope, the
+// sub-proof's commitment must be C - threshold*B.  thread = envelope
+ZKP_HD inline void step_vparse_threshold(const VfyView& V, uint32_t i, const uint8_t* env, uint64_t env_off, uint32_t len, uint64_t threshold) {
+    V.kind[i] = KIND_THRESHOLD; V.proof_off[i] = 0; V.venc_off[i] = 0; V.bad[i] = 1;
+    if (len < 10 || len > 1024u * 1024u || env[0] != 2 || env[1] != 3) return;
+    const uint32_t bl = ld_u32(env + 2), cl = ld_u32(env + 6);
+    if (bl > 900u * 1024u || cl != 32 || (uint64_t)10 + bl + cl != len) return;
+    const uint8_t* body = env + 10; const uint8_t* comm = env + 10 + bl;
+    if (bl < 12 || ld_u64(body) != threshold) return;
+    const uint32_t n_bits = ld_u32(body + 8);
+    if (bl < 16) return;
+    const uint32_t rl = ld_u32(body + 12);
+    if (bl - 16 < rl || bl - 16 - rl < 32) return;
+    if (!(n_bits == 8 || n_bits == 16 || n_bits == 32 || n_bits == 64)) return;
+    const uint8_t* dc = body + 16 + rl;
+    ge d, sp; uint32_t wd[8], wsp[8];
+    ld_bytes_words(wd, dc, 8); ld_bytes_words(wsp, comm, 8);
+    if (!ge_ristretto_decode(d, wd) || !ge_ristretto_decode(sp, wsp)) return;
+    ge tb = ge_identity();
+    uint32_t dt[DIGW];
+    sc_recode_signed1024(dt, sc_words((uint32_t)threshold, (uint32_t)(threshold >> 32), 0, 0, 0, 0, 0, 0));
+    for (uint32_t win = 0; win < NWIN_U64; win++) {
+        const int32_t a = (int32_t)(int16_t)(dt[win >> 1] >> (16 * (win & 1)));
+        if (a != 0) tb = msm_accumulate_digit(tb, a, V.table + ((size_t)BASE_B * NWIN + win) * SUBTAB_W);
+    }
+    uint32_t e[8];
+    ge_ristretto_encode(e, ge_add(sp, ge_neg(tb)));
+    for (int k = 0; k < 8; k++) if (e[k] != wd[k]) return;
+    if (n_bits != 64) { V.bad[i] = VFY_UNSUPPORTED; return; }
+    if (rl != RP_BYTES) return;
+    V.proof_off[i] = env_off + 10 + 16; V.venc_off[i] = env_off + 10 + 16 + rl; V.bad[i] = 0;
+}
+
 // ---- step 1: decode the 17 points of a job.  thread = (p, job)
 ZKP_HD inline void step_vdecode(const VfyView& V, uint32_t p, uint32_t job) {
     if (V.bad[job]) return;
@@ -169,7 +202,11 @@ ZKP_HD inline void step_vtranscript(const VfyView& V, uint32_t job, Strobe& s) {
     ld_bytes_words(r_tx.v, pr + 128, 8); ld_bytes_words(r_txb.v, pr + 160, 8); ld_bytes_words(r_eb.v, pr + 192, 8);
     ld_bytes_words(r_a.v, pr + 608, 8); ld_bytes_words(r_b.v, pr + 640, 8);
     if (!sc_raw_is_canonical(r_tx) || !sc_raw_is_canonical(r_txb) || !sc_raw_is_canonical(r_eb) || !sc_raw_is_canonical(r_a) || !sc_raw_is_canonical(r_b)) { V.bad[job] = 1; return; }
-    if (V.kind[job] == KIND_RANGE_MIN) merlin_init(s, "libzkp_range_min", 16); else merlin_init(s, "libzkp_range_max", 16);
+    switch (V.kind[job]) {
+        case KIND_RANGE_MIN: merlin_init(s, "libzkp_range_min", 16); break;
+        case KIND_RANGE_MAX: merlin_init(s, "libzkp_range_max", 16); break;
+        default: merlin_init(s, "libzkp_threshold", 16); break;
+    }
     merlin_append_bytes(s, "dom-sep", 7, "rangeproof v1", 13);
     merlin_append_u64(s, "n", 1, BP_N);
     merlin_append_u64(s, "m", 1, 1);
@@ -257,10 +294,10 @@ ZKP_HD inline void step_vvarbase(const VfyView& V, uint32_t p, uint32_t job) {
     st_ge(V.partial, V.var_chunk0 + p, job, M, r);
 }
 
-// ---- step 5: verdict.  thread = envelope; enc = [1][8][M] encodings of the per-job sums
-ZKP_HD inline void step_vfinal(const VfyView& V, const uint32_t* enc, uint32_t i, uint8_t* ok) {
+// ---- step 5: verdict.  thread = envelope (jobs_per = 2 for range, 1 for threshold); enc = [1][8][M] encodings of the per-job sums
+ZKP_HD inline void step_vfinal(const VfyView& V, const uint32_t* enc, uint32_t i, uint8_t* ok, uint32_t jobs_per) {
     uint32_t verdict = 1;
-    for (uint32_t j = 2 * i; j < 2 * i + 2; j++) {
+    for (uint32_t j = jobs_per * i; j < jobs_per * (i + 1); j++) {
         if (V.bad[j] == VFY_UNSUPPORTED) { verdict = VFY_UNSUPPORTED; break; }
         uint32_t o = 0; for (int k = 0; k < 8; k++) o |= enc[(size_t)k * V.M + j];
         if (V.bad[j] || o != 0) verdict = 0;

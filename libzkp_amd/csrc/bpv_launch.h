@@ -4,8 +4,9 @@
 #include "bp_verify.h"
 
 void bpv_launch_parse(const zkp::VfyView& V, uint32_t n, uint64_t stride, const uint32_t* d_len, const uint64_t* d_min, const uint64_t* d_max, hipStream_t st);
+void bpv_launch_parse_threshold(const zkp::VfyView& V, uint32_t n, uint64_t stride, const uint32_t* d_len, const uint64_t* d_thr, hipStream_t st);
 void bpv_launch_decode(const zkp::VfyView& V, hipStream_t st);
 void bpv_launch_transcript(const zkp::VfyView& V, hipStream_t st);
 void bpv_launch_scalars(const zkp::VfyView& V, hipStream_t st);
 void bpv_launch_varbase(const zkp::VfyView& V, hipStream_t st);
-void bpv_launch_final(const zkp::VfyView& V, const uint32_t* d_enc, uint32_t n, uint8_t* d_ok, hipStream_t st);
+void bpv_launch_final(const zkp::VfyView& V, const uint32_t* d_enc, uint32_t n, uint8_t* d_ok, uint32_t jobs_per, hipStream_t st);

@@ -111,7 +111,7 @@ int emul_verify_range_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, 
     const uint16_t tcb[2] = {0, (uint16_t)(L.nchunks() + VP_NUM)};
     ReduceView r; r.rows = M; r.ntargets = 1; r.partial = partial.data(); r.target_chunk_begin = tcb; r.enc = enc.data(); r.out_off = nullptr; r.out = nullptr; r.corr = nullptr;
     for (uint32_t j = 0; j < M; j++) reduce_encode_thread(r, 0, j);
-    for (uint32_t i = 0; i < n; i++) step_vfinal(V, enc.data(), i, ok);
+    for (uint32_t i = 0; i < n; i++) step_vfinal(V, enc.data(), i, ok, 2);
     return 0;
 }
 // k * P on ristretto encodings (decode, signed radix-4 multiplication, encode); 0 if the encoding is invalid

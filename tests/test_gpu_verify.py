@@ -88,3 +88,29 @@ def test_full_batch_of_4096(hip):
     t0 = time.perf_counter(); ok = gpu_verify(hip, out, lens, mn, mx); dt = time.perf_counter() - t0
     assert (ok == 1).all()
     print("verified 4096 range envelopes in %.2f ms (host buffers)" % (dt * 1e3))
+
+
+def test_threshold_verification_matches_oracle(hip, oracle_c):
+    import ctypes
+    import libzkp_amd as z
+    rng = np.random.default_rng(17)
+    n = 64
+    lists = [[int(x) for x in rng.integers(0, 2**40, int(k))] for k in rng.integers(1, 6, n)]
+    ths = [int(rng.integers(0, sum(v) + 1)) for v in lists]
+    ths[0] = sum(lists[0])                                     # tight: sum == threshold
+    proofs = z.prove_threshold_batch(lists, ths, seeds=bytes(rng.integers(0, 256, 32 * n, dtype=np.uint8)))
+    assert all(len(p) == 762 for p in proofs)
+    assert z.verify_threshold_batch(proofs, ths) == [True] * n
+    assert z.verify_threshold_batch(proofs, [t + 1 for t in ths]) == [False] * n          # wrong threshold
+    # tampering: verdicts equal the oracle's
+    orc = oracle_c
+    orc.zkp_oracle_verify_threshold.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint64]
+    bad = []
+    for i, p in enumerate(proofs):
+        b = bytearray(p); b[int(rng.integers(0, 762))] ^= 1 << int(rng.integers(0, 8)); bad.append(bytes(b))
+    want = [bool(orc.zkp_oracle_verify_threshold(b, len(b), ths[i])) for i, b in enumerate(bad)]
+    assert z.verify_threshold_batch(bad, ths) == want and not any(want)
+    assert [bool(orc.zkp_oracle_verify_threshold(p, len(p), ths[i])) for i, p in enumerate(proofs[:8])] == [True] * 8
+    assert z.verify_threshold(proofs[3], ths[3]) and not z.verify_threshold(proofs[3][:-1], ths[3]) and not z.verify_threshold(b"", 0)
+    # a range envelope is not a threshold envelope
+    assert not z.verify_threshold(z.prove_range(5, 0, 10), 0)
