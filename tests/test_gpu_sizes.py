@@ -83,3 +83,35 @@ def test_improvement_sizes(hip, n):
     for i in range(0, n, max(1, n // 50)):
         want = hashlib.sha256(b"libzkp_improvement_v1" + int(olds[i]).to_bytes(8, "little") + int(news[i]).to_bytes(8, "little")).digest()
         assert out[i, lens[i] - 32:lens[i]].tobytes() == want
+
+
+def test_concurrent_callers(hip, oracle_c):
+    """The reference calls its backends from rayon workers (batch.rs:125-130): concurrent calls into the C ABI from
+    several host threads must each get their own, correct results (the library serialises device work internally)."""
+    import threading
+    results, errors = {}, []
+
+    def worker(t):
+        try:
+            n = 40 + 7 * t
+            v, mn, mx, seeds = workload(n, 900 + t)
+            out = np.zeros((n, 1478), dtype=np.uint8); lens = np.zeros(n, dtype=np.uint32); st = np.zeros(n, dtype=np.int32)
+            for _ in range(3):
+                assert hip.zkp_hip_prove_range_batch(n, P(v), P(mn), P(mx), 64, P(seeds), P(out), 1478, P(lens), P(st)) == 0
+                olds = np.arange(1, n + 1, dtype=np.uint64) * (t + 1); news = olds + 5
+                so = np.zeros((n, 3527), dtype=np.uint8); sl = np.zeros(n, dtype=np.uint32); ss = np.zeros(n, dtype=np.int32)
+                assert hip.zkp_hip_prove_improvement_batch(n, P(olds), P(news), P(so), 3527, P(sl), P(ss)) == 0
+            results[t] = (v, mn, mx, seeds, out.copy(), so[0, :sl[0]].tobytes(), int(olds[0]), int(news[0]))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t, (v, mn, mx, seeds, out, sp, o, w) in results.items():
+        rc, ref, _, _ = oracle_prove(oracle_c, v, mn, mx, seeds)
+        assert rc == 0 and (out == ref).all(), t
+        assert sp == stark.prove_improvement(o, w)
