@@ -174,6 +174,8 @@ struct Ctx {
     int num_cu = 256, msm_blocks_per_cu = 3;
     hipStream_t stream = nullptr;
     hipEvent_t start_ev = nullptr;
+    hipStream_t side = nullptr;                    // the commitment tasks of a batch (independent of its proofs) run beside the first phase
+    hipEvent_t side_go = nullptr, side_done = nullptr;
     uint32_t* d_table = nullptr;
     LayoutSet p1, p2, rd[6], ct;
     uint32_t max_chunks = 0;
@@ -277,6 +279,9 @@ int init_locked(int device) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_msm_dma<EdMsm>, EdMsm::TB, msm_lds_bytes<EdMsm>()) == hipSuccess && occ > 0) g.msm_blocks_per_cu = occ;
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&g.start_ev, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&g.side_go, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&g.side_done, hipEventDisableTiming));
     // generator tables (one-time, host)
     const size_t words = (size_t)NBASE * NWIN * SUBTAB_W;
     std::vector<uint32_t> tab(words);
@@ -395,9 +400,15 @@ int msm_and_encode(const LayoutSet& S, uint32_t rows, const uint32_t* digits, ui
 int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st) {
     int rc;
     const dim3 gj((M + TB - 1) / TB), gw((M + TW - 1) / TW);
+    // The commitment tasks (one small MSM, one inverse-square-root chain on C/64 waves) depend on nothing the proofs compute:
+    // they go to a side stream and overlap the tape / first MSM instead of standing in front of them.
+    const bool forked = C != 0 && M != 0;
     if (C) {
-        k_ctask<<<(C + TB - 1) / TB, TB, 0, st>>>(w.T);
-        if ((rc = msm_and_encode(g.ct, C, w.T.digits, w.ct_partial, w.ct_sums, w.ct_enc, w.ct_off, w.V.out, st))) return rc;
+        hipStream_t cs = forked ? g.side : st;
+        if (forked) { HIP_TRY(hipEventRecord(g.side_go, st)); HIP_TRY(hipStreamWaitEvent(cs, g.side_go, 0)); }
+        k_ctask<<<(C + TB - 1) / TB, TB, 0, cs>>>(w.T);
+        if ((rc = msm_and_encode(g.ct, C, w.T.digits, w.ct_partial, w.ct_sums, w.ct_enc, w.ct_off, w.V.out, cs))) return rc;
+        if (forked) HIP_TRY(hipEventRecord(g.side_done, cs));
     }
     if (M == 0) { HIP_TRY(hipGetLastError()); return 0; }
     k_tape<<<dim3(gj.x, TAPE_SLOTS + 1), TB, 0, st>>>(w.V);
@@ -414,6 +425,7 @@ int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st) {
         if ((rc = msm_and_encode(g.rd[r], M, w.V.dr, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
         k_transcript_round<<<gw, TW, 0, st>>>(w.V, r);
     }
+    if (forked) HIP_TRY(hipStreamWaitEvent(st, g.side_done, 0));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -552,6 +564,7 @@ void zkp_hip_shutdown(void) {
     for (auto& d : g.rd) free_set(d);
     for (auto& e : g.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     (void)hipEventDestroy(g.start_ev);
+    (void)hipStreamDestroy(g.side); (void)hipEventDestroy(g.side_go); (void)hipEventDestroy(g.side_done);
     (void)hipStreamDestroy(g.stream);
     g = Ctx();
 }
