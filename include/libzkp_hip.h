@@ -123,6 +123,12 @@ int zkp_hip_prove_improvement_batch(uint64_t n, const uint64_t* old_values, cons
 int zkp_hip_prove_improvement_batch_device(uint64_t n, const uint64_t* d_old, const uint64_t* d_new, uint8_t* d_out, uint64_t stride,
                                            uint32_t* d_out_len, void* stream);
 
+/* Replaces a loop of proof::improvement_proof::verify_improvement(proof, old) (improvement_proof.rs:37-68 ->
+ * StarkBackend::verify, stark.rs:190-211,237-255): ok[i] = 1 accepted / 0 rejected (framing, stored old != old, binding
+ * commitment, transcript-derived checks, Merkle openings, DEEP / remainder consistency). */
+int zkp_hip_verify_improvement_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, const uint32_t* lens,
+                                     const uint64_t* old_values, uint8_t* ok);
+
 /* Replaces a loop of proof::set_membership::prove_membership(value, set) (set_membership.rs:12-38 ->
  * SnarkBackend::prove_membership_zk, snark.rs:405-452).  sets = all ops' sets concatenated, set_counts[i] <= 64.
  * Envelope (scheme 4) = 10 + 4 + 8*len + 256 + 32 bytes; stride >= the largest. */

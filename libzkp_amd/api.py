@@ -404,6 +404,30 @@ def verify_threshold_batch(proofs, thresholds):
     return [bool(x) for x in ok]
 
 
+def verify_improvement_batch(proofs, olds):
+    """Batched verify_improvement (improvement_proof.rs:37-68): list of bools."""
+    n = len(proofs)
+    if len(olds) != n:
+        raise ValueError("proofs, olds must have equal length")
+    if n == 0:
+        return []
+    ov = np.array([_check_u64("old", x) for x in olds], dtype=np.uint64)
+    blobs = [bytes(p) for p in proofs]
+    stride = min(8192, max(16, max(len(b) for b in blobs)))
+    buf = np.zeros((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint32)
+    for i, b in enumerate(blobs):
+        lens[i] = len(b)
+        buf[i, : min(len(b), stride)] = np.frombuffer(b[:stride], dtype=np.uint8)
+    ok = np.zeros(n, dtype=np.uint8)
+    _native.check(_native.lib().zkp_hip_verify_improvement_batch(n, _P(buf), stride, _P(lens), _P(ov), _P(ok)), "zkp_hip_verify_improvement_batch")
+    return [bool(x) for x in ok]
+
+
+def verify_improvement(proof, old):
+    return verify_improvement_batch([proof], [old])[0]
+
+
 def verify_threshold(proof, threshold):
     return verify_threshold_batch([proof], [threshold])[0]
 

@@ -432,4 +432,186 @@ ZKP_HD inline void stark_prove(StarkMem& M, const StarkConst& C, uint64_t oldv, 
     stark_step_finish(M, C, oldv, newv, tid); sync();
 }
 
+// ---------------------------------------------------------------------------------------------- the verifier
+// proof::improvement_proof::verify_improvement (improvement_proof.rs:37-68) -> StarkBackend::verify (stark.rs:190-211,
+// 237-255), restated in oracle/py/stark.py: verify_improvement / verify.  One thread verifies one envelope (a few hundred
+// BLAKE3 compressions and field products); every check is a cross-multiplied identity, so no field inversion is needed.
+struct StarkReader {
+    const uint8_t* b; uint32_t p, n; bool ok;
+    ZKP_HD const uint8_t* take(uint32_t k) { if (!ok || n - p < k) { ok = false; return b; } const uint8_t* r = b + p; p += k; return r; }
+    ZKP_HD uint32_t u8() { const uint8_t* r = take(1); return ok ? r[0] : 0u; }
+    ZKP_HD uint32_t u16() { const uint8_t* r = take(2); return ok ? (uint32_t)r[0] | ((uint32_t)r[1] << 8) : 0u; }
+    ZKP_HD uint32_t vint() {                       // winter-utils variable-length usize (values here are < 2^21: at most 3 bytes)
+        if (!ok || p >= n) { ok = false; return 0; }
+        const uint32_t first = b[p];
+        if (first == 0) { ok = false; return 0; }
+        uint32_t nb = 1; while (((first >> (nb - 1)) & 1u) == 0) nb++;
+        if (nb > 4) { ok = false; return 0; }
+        const uint8_t* r = take(nb); if (!ok) return 0;
+        uint32_t v = 0; for (uint32_t i = 0; i < nb; i++) v |= (uint32_t)r[i] << (8 * i);
+        return v >> nb;
+    }
+    ZKP_HD f128 element() {
+        const uint8_t* r = take(16); f128 v = f128_make(0);
+        if (!ok) return v;
+        for (int i = 0; i < 8; i++) { v.lo |= (uint64_t)r[i] << (8 * i); v.hi |= (uint64_t)r[8 + i] << (8 * i); }
+        if (f128_geq_p(v)) ok = false;
+        return v;
+    }
+};
+ZKP_HD inline void ld_digest(uint32_t d[8], const uint8_t* p) { for (int i = 0; i < 8; i++) d[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24); }
+struct StarkQueries { f128 val[32]; const uint8_t* list[32]; uint8_t cnt[32]; uint32_t nlists, depth; };
+ZKP_HD_NOINLINE inline void stark_read_queries(StarkReader& r, uint32_t nq, StarkQueries& q) {
+    if (r.vint() != 16 * nq) r.ok = false;
+    for (uint32_t i = 0; i < nq && r.ok; i++) q.val[i] = r.element();
+    const uint32_t olen = r.vint(), end = r.p + olen;
+    q.depth = r.u8(); q.nlists = r.vint();
+    if (q.nlists > 32) r.ok = false;
+    for (uint32_t k = 0; k < q.nlists && r.ok; k++) { q.cnt[k] = (uint8_t)r.u8(); q.list[k] = r.take(32u * q.cnt[k]); }
+    if (r.p != end) r.ok = false;
+}
+// root of the batch opening (oracle/py/stark.py: batch_root); false if the node lists do not fit the opened positions
+ZKP_HD_NOINLINE inline bool stark_batch_root(uint32_t root[8], const StarkQueries& q, uint64_t mask) {
+    uint32_t val[32][8]; uint8_t idx[32], ptr[32];
+    uint32_t npairs = 0, k_leaf = 0;
+    for (uint32_t pr = 0; pr < STARK_LDE; pr += 2) {
+        const uint32_t a = (uint32_t)(mask >> pr) & 1u, b = (uint32_t)(mask >> (pr + 1)) & 1u;
+        if (!(a | b)) continue;
+        if (npairs >= q.nlists) return false;
+        ptr[npairs] = 0;
+        uint32_t v[2][8];
+        for (uint32_t s = 0; s < 2; s++) {
+            if (s == 0 ? a : b) { uint32_t w[4]; f128_words(w, q.val[k_leaf++]); blake3_words(v[s], w, 4); }
+            else { if (ptr[npairs] >= q.cnt[npairs]) return false; ld_digest(v[s], q.list[npairs] + 32u * ptr[npairs]); ptr[npairs]++; }
+        }
+        idx[npairs] = (uint8_t)((pr + STARK_LDE) >> 1);
+        blake3_merge(val[npairs], v[0], v[1]);
+        npairs++;
+    }
+    if (npairs != q.nlists) return false;
+    uint32_t ncur = npairs;
+    for (uint32_t level = 1; level < STARK_DEPTH; level++) {
+        uint32_t nn = 0, i = 0;
+        while (i < ncur) {
+            const uint32_t sib = idx[i] ^ 1u;
+            uint32_t out[8];
+            if (i + 1 < ncur && idx[i + 1] == sib) { blake3_merge(out, val[i], val[i + 1]); i++; }
+            else {
+                if (ptr[i] >= q.cnt[i]) return false;
+                uint32_t sv[8]; ld_digest(sv, q.list[i] + 32u * ptr[i]); ptr[i]++;
+                if ((idx[i] & 1u) == 0) blake3_merge(out, val[i], sv); else blake3_merge(out, sv, val[i]);
+            }
+            // slot nn <= i - (pairs consumed so far) is never ahead of the read position, so writing in place is safe
+            for (int w = 0; w < 8; w++) val[nn][w] = out[w];
+            idx[nn] = (uint8_t)(sib >> 1);
+            nn++; i++;
+        }
+        ncur = nn;
+    }
+    if (ncur != 1) return false;
+    for (uint32_t k = 0; k < npairs; k++) if (ptr[k] != q.cnt[k]) return false;
+    for (int w = 0; w < 8; w++) root[w] = val[0][w];
+    return true;
+}
+ZKP_HD_NOINLINE inline bool stark_verify_envelope(const uint8_t* env, uint32_t len, uint64_t old_expected, const StarkConst& C) {
+    if (len < 10 || env[0] != 2 || env[1] != 5) return false;
+    uint32_t plen = 0, clen = 0;
+    for (int i = 0; i < 4; i++) { plen |= (uint32_t)env[2 + i] << (8 * i); clen |= (uint32_t)env[6 + i] << (8 * i); }
+    if ((uint64_t)10 + plen + clen != len || plen < 16 || clen != 32) return false;
+    uint64_t oldv = 0, newv = 0;
+    for (int i = 0; i < 8; i++) { oldv |= (uint64_t)env[10 + i] << (8 * i); newv |= (uint64_t)env[18 + i] << (8 * i); }
+    if (oldv != old_expected || newv <= oldv) return false;
+    uint8_t cm[32]; improvement_commitment(cm, oldv, newv);
+    for (int i = 0; i < 32; i++) if (cm[i] != env[10 + plen + i]) return false;
+    // ---- parse
+    StarkReader r{env + 26, 0, plen - 16, true};
+    const uint8_t* ctx = r.take(28);
+    if (!r.ok) return false;
+    for (int i = 0; i < 28; i++) if (ctx[i] != C.context_bytes[i]) return false;
+    const uint32_t nq = r.u8();
+    if (r.u16() != 96) return false;
+    const uint8_t* roots = r.take(96);
+    if (!r.ok || nq < 1 || nq > STARK_QUERIES) return false;
+    StarkQueries tq, hq;
+    stark_read_queries(r, nq, tq); stark_read_queries(r, nq, hq);
+    if (!r.ok || r.u16() != 33 || r.u8() != 2) return false;
+    const f128 tz = r.element(), tzg = r.element();
+    if (r.u16() != 16) return false;
+    const f128 hz = r.element();
+    if (r.u8() != 0 || r.u16() != 128) return false;
+    f128 rem[8]; for (int i = 0; i < 8; i++) rem[i] = r.element();
+    if (r.u8() != 1) return false;
+    const uint8_t* tail = r.take(9);
+    if (!r.ok || r.p != r.n) return false;
+    for (int i = 0; i < 9; i++) if (tail[i] != 0) return false;
+    if (tq.depth != STARK_DEPTH || hq.depth != STARK_DEPTH) return false;
+    // ---- coin replay
+    StarkMem* none = nullptr; (void)none;
+    uint32_t seed[8]; uint64_t counter = 0;
+    auto reseed = [&](const uint32_t d[8]) { uint32_t s2[8]; blake3_merge(s2, seed, d); for (int i = 0; i < 8; i++) seed[i] = s2[i]; counter = 0; };
+    auto draw = [&]() -> f128 {
+        for (int tries = 0; tries < 1000; tries++) {
+            uint32_t d[8]; counter++; blake3_merge_int(d, seed, counter);
+            f128 v; v.lo = (uint64_t)d[0] | ((uint64_t)d[1] << 32); v.hi = (uint64_t)d[2] | ((uint64_t)d[3] << 32);
+            if (!f128_geq_p(v)) return v;
+        }
+        return f128_make(0);
+    };
+    const f128 o = f128_make(oldv), nw = f128_make(newv), step = f128_mul(f128_sub(nw, o), C.inv7);
+    {
+        uint32_t w[40];
+        for (int i = 0; i < 32; i++) w[i] = C.seed_prefix[i];
+        f128_words(w + 32, o); f128_words(w + 36, nw);
+        blake3_words(seed, w, 40);
+    }
+    uint32_t t_root[8], h_root[8], rem_commit[8];
+    ld_digest(t_root, roots); ld_digest(h_root, roots + 32); ld_digest(rem_commit, roots + 64);
+    reseed(t_root);
+    const f128 c0 = draw(), c1 = draw(), c2 = draw();
+    reseed(h_root);
+    const f128 z = draw(), zg = f128_mul(z, C.g);
+    uint32_t d[8];
+    { const f128 e[2] = {tz, tzg}; blake3_elements(d, e, 2); reseed(d); }
+    // out-of-domain consistency, cross-multiplied by (z^8 - 1)(z - 1)(z - g^7)
+    {
+        const f128 one = f128_make(1);
+        f128 z8 = z; for (int k = 0; k < 3; k++) z8 = f128_mul(z8, z8);
+        const f128 a = f128_sub(z8, one), b = f128_sub(z, one), c = f128_sub(z, C.g_last);
+        const f128 lhs = f128_mul(f128_mul(hz, a), f128_mul(b, c));
+        const f128 t = f128_mul(f128_mul(c0, f128_sub(f128_sub(tzg, tz), step)), f128_mul(f128_mul(c, c), b));
+        const f128 b0 = f128_mul(f128_mul(c1, f128_sub(tz, o)), f128_mul(a, c));
+        const f128 b1 = f128_mul(f128_mul(c2, f128_sub(tz, nw)), f128_mul(a, b));
+        const f128 rhs = f128_add(f128_add(t, b0), b1);
+        if (lhs.lo != rhs.lo || lhs.hi != rhs.hi) return false;
+    }
+    blake3_elements(d, &hz, 1); reseed(d);
+    const f128 dc0 = draw(), dc1 = draw();
+    blake3_elements(d, rem, 8);
+    for (int i = 0; i < 8; i++) if (d[i] != rem_commit[i]) return false;
+    reseed(rem_commit);
+    { uint32_t s2[8]; blake3_merge_int(s2, seed, 0); for (int i = 0; i < 8; i++) seed[i] = s2[i]; counter = 0; }
+    uint64_t mask = 0;
+    for (uint32_t q = 0; q < STARK_QUERIES; q++) { counter++; blake3_merge_int(d, seed, counter); mask |= 1ull << (d[0] & (STARK_LDE - 1)); }
+    uint32_t count = 0; for (uint32_t i = 0; i < STARK_LDE; i++) count += (uint32_t)(mask >> i) & 1u;
+    if (count != nq) return false;
+    // ---- Merkle openings
+    uint32_t root[8];
+    if (!stark_batch_root(root, tq, mask)) return false;
+    for (int i = 0; i < 8; i++) if (root[i] != t_root[i]) return false;
+    if (!stark_batch_root(root, hq, mask)) return false;
+    for (int i = 0; i < 8; i++) if (root[i] != h_root[i]) return false;
+    // ---- DEEP composition on the committed remainder polynomial, cross-multiplied by (x - z)(x - z g)
+    uint32_t k = 0;
+    for (uint32_t pos = 0; pos < STARK_LDE; pos++) {
+        if (!((mask >> pos) & 1u)) continue;
+        const f128 x = C.x_lde[pos], tv = tq.val[k], hv = hq.val[k];
+        k++;
+        const f128 xz = f128_sub(x, z), xzg = f128_sub(x, zg);
+        const f128 lhs = f128_add(f128_mul(dc0, f128_add(f128_mul(f128_sub(tv, tz), xzg), f128_mul(f128_sub(tv, tzg), xz))), f128_mul(dc1, f128_mul(f128_sub(hv, hz), xzg)));
+        const f128 rhs = f128_mul(stark_horner8(rem, x), f128_mul(xz, xzg));
+        if (lhs.lo != rhs.lo || lhs.hi != rhs.hi) return false;
+    }
+    return true;
+}
+
 }  // namespace zkp

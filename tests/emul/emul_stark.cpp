@@ -23,4 +23,8 @@ uint32_t emul_stark_prove(uint64_t oldv, uint64_t newv, uint8_t* out, uint32_t c
     return M.out_len;
 }
 uint32_t emul_stark_max_envelope() { return STARK_MAX_ENVELOPE; }
+int emul_stark_verify(const uint8_t* env, uint32_t len, uint64_t oldv) {
+    if (!g_ready) { stark_build_constants(g_c); g_ready = true; }
+    return stark_verify_envelope(env, len, oldv, g_c) ? 1 : 0;
+}
 }

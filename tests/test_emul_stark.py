@@ -68,3 +68,22 @@ def test_envelopes_equal_oracle(lib):
         assert bytes(buf[:n]) == want, (old, new)
         lens.add(n)
     assert len(lens) > 1          # the proof length really varies with the number of distinct query positions
+
+
+def test_verifier_verdicts_equal_oracle(lib):
+    """stark_verify_envelope (the GPU verifier's code, on the host) against oracle.verify_improvement: valid proofs, a wrong
+    `old`, truncations, and a flipped bit at every ninth byte of several envelopes."""
+    lib.emul_stark_verify.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint64]
+    rnd = random.Random(5)
+    n = 0
+    for old, new in [(100, 250), (0, 1), (5, 2**63), (0, 2**64 - 1), (2**64 - 2, 2**64 - 1)]:
+        env = s.prove_improvement(old, new)
+        assert lib.emul_stark_verify(env, len(env), old) == 1
+        assert lib.emul_stark_verify(env, len(env), old + 1) == 0
+        for i in range(rnd.randrange(9), len(env), 9):
+            bad = bytearray(env); bad[i] ^= 1 << rnd.randrange(8)
+            assert bool(lib.emul_stark_verify(bytes(bad), len(bad), old)) == s.verify_improvement(bytes(bad), old), (old, new, i)
+            n += 1
+        for cut in (0, 1, 9, 10, 30, len(env) - 1):
+            assert lib.emul_stark_verify(env[:cut], cut, old) == 0
+    assert n > 1400

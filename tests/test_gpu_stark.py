@@ -109,3 +109,22 @@ def test_device_pointer_entry(hip):
     out, ln = d_out.cpu().numpy(), d_len.cpu().numpy()
     for i in (0, 100, 255):
         assert out[i, :ln[i]].tobytes() == s.prove_improvement(int(olds[i]), int(news[i]))
+
+
+def test_verification_matches_oracle(hip):
+    import libzkp_amd as z
+    rng = np.random.default_rng(23)
+    n = 200
+    olds = rng.integers(0, 2**63, n, dtype=np.uint64)
+    news = olds + 1 + rng.integers(0, 2**32, n, dtype=np.uint64)
+    rc, proofs, st = run(hip, olds, news)
+    assert rc == 0
+    assert z.verify_improvement_batch(proofs, [int(x) for x in olds]) == [True] * n
+    assert z.verify_improvement_batch(proofs, [int(x) + 1 for x in olds]) == [False] * n
+    bad = []
+    for p in proofs:
+        b = bytearray(p); b[int(rng.integers(0, len(p)))] ^= 1 << int(rng.integers(0, 8)); bad.append(bytes(b))
+    want = [s.verify_improvement(b, int(o)) for b, o in zip(bad, olds)]
+    assert z.verify_improvement_batch(bad, [int(x) for x in olds]) == want and not any(want)
+    assert not z.verify_improvement(b"", 0) and not z.verify_improvement(proofs[0][:-1], int(olds[0]))
+    assert z.verify_improvement(s.prove_improvement(30, 50), 30)                  # an oracle-made proof
