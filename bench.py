@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="batches in flight: step k is issued on caller stream k %% P with its own output buffers (1 = strictly one after another; "
+                         "the library keeps at most 2 in flight)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the driver's runs) or gloo (rehearsing N > 1 on a box with fewer GPUs)")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--window-budget", type=int, default=0)
     ap.add_argument("--subbatches", type=int, default=0)
@@ -100,9 +104,14 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP prover has no CPU fallback")
+    if os.environ.get("ZKP_BENCH_DEVICE") is not None:          # rehearsal only: several ranks on one GPU
+        local_rank = int(os.environ["ZKP_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from libzkp_amd import _native
     L = _native.lib()
@@ -121,16 +130,23 @@ def main():
     d_mn = torch.from_numpy(mn.view(np.int64)).to(dev)
     d_mx = torch.from_numpy(mx.view(np.int64)).to(dev)
     d_seeds = torch.from_numpy(seeds).to(dev)
-    d_out = torch.zeros((n, PROOF_BYTES), dtype=torch.uint8, device=dev)
-    d_len = torch.zeros(n, dtype=torch.int32, device=dev)
-    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
-    stream = torch.cuda.Stream(device=dev)   # non-default stream: its handle is non-NULL, so the library launches on it
+    P = max(1, min(args.pipeline, 2))
+    outs = [(torch.zeros((n, PROOF_BYTES), dtype=torch.uint8, device=dev), torch.zeros(n, dtype=torch.int32, device=dev),
+             torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(P)]
+    d_out, d_len, d_st = outs[0]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(P)]   # non-default streams: their handles are non-NULL, so the library orders its work on them
+    stream = streams[0]
+    issued = [0]
 
     def step():
+        k = issued[0] % P
+        issued[0] += 1
+        o, ln, stt = outs[k]
         rc = L.zkp_hip_prove_range_batch_device(n, d_v.data_ptr(), d_mn.data_ptr(), d_mx.data_ptr(), 64, d_seeds.data_ptr(),
-                                                d_out.data_ptr(), PROOF_BYTES, d_len.data_ptr(), d_st.data_ptr(),
-                                                ctypes.c_void_p(stream.cuda_stream), None)
+                                                o.data_ptr(), PROOF_BYTES, ln.data_ptr(), stt.data_ptr(),
+                                                ctypes.c_void_p(streams[k].cuda_stream), None)
         _native.check(rc, "zkp_hip_prove_range_batch_device")
+        return streams[k]
 
     def barrier():
         torch.cuda.synchronize()
@@ -144,24 +160,28 @@ def main():
     barrier()
     L.zkp_hip_profile_enable(1)
     L.zkp_hip_profile_read(None, None, None, 1)
+    issued[0] = 0
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     evs[0].record(stream)
     for k in range(args.steps):
-        step()
-        evs[k + 1].record(stream)
+        evs[k + 1].record(step())
     barrier()
     dt = time.perf_counter() - t0
     msm_ms, msm_launches, msm_adds = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
     L.zkp_hip_profile_read(ctypes.byref(msm_ms), ctypes.byref(msm_launches), ctypes.byref(msm_adds), 1)
     L.zkp_hip_profile_enable(0)
-    step_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps)]
+    if P == 1:
+        step_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps)]
+    else:            # batches overlap: per-batch completion intervals alternate, so report the mean interval
+        step_ms = [dt / args.steps * 1e3]
 
     # correctness guard inside the bench: every op succeeded
-    assert int(d_st.abs().sum().item()) == 0 and int((d_len != PROOF_BYTES).sum().item()) == 0
+    for o, ln, stt in outs:
+        assert int(stt.abs().sum().item()) == 0 and int((ln != PROOF_BYTES).sum().item()) == 0
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -185,7 +205,8 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (25.5-bit radix GF(2^255-19), 8x32 Montgomery mod l)", "data": "synthetic",
             "config": {"workload": "process_batch of %d prove_range(v, 0, 2^32), n_bits=64, seed 1 (BASELINE.md C2)" % n,
-                       "ops_per_gpu_per_step": n, "proof_bytes": PROOF_BYTES, "sharding": "independent ops per rank, no collective"},
+                       "ops_per_gpu_per_step": n, "proof_bytes": PROOF_BYTES, "sharding": "independent ops per rank, no collective",
+                       "batches_in_flight": P},
             "ms_per_proof_p50": statistics.median(step_ms) / n,
             "ms_per_batch_p50": statistics.median(step_ms),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -163,23 +163,26 @@ struct LayoutSet { std::vector<DevLayout> cand; uint32_t max_chunks = 0; };
 
 struct SubBatch {
     hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;
+    hipEvent_t start = nullptr, done = nullptr;
+    hipStream_t side = nullptr;                    // the commitment tasks of a batch (independent of its proofs) run beside the first phase
+    hipEvent_t side_go = nullptr, side_done = nullptr;
+    bool used = false;                             // `done` has been recorded at least once
     void* ws = nullptr;
     uint32_t capM = 0, capC = 0;
 };
+constexpr uint32_t NSLOTS = 2;      // device-pointer calls alternate between two sets of streams + workspace, so a caller that
+                                    // feeds batches from two of its own streams keeps two batches in flight (bench.py --pipeline 2)
 
 struct Ctx {
     bool ready = false;
     int device = 0;
     int num_cu = 256, msm_blocks_per_cu = 3;
     hipStream_t stream = nullptr;
-    hipEvent_t start_ev = nullptr;
-    hipStream_t side = nullptr;                    // the commitment tasks of a batch (independent of its proofs) run beside the first phase
-    hipEvent_t side_go = nullptr, side_done = nullptr;
     uint32_t* d_table = nullptr;
     LayoutSet p1, p2, rd[6], ct;
     uint32_t max_chunks = 0;
-    std::vector<SubBatch> sub;
+    std::vector<SubBatch> sub;          // [slot * nsub + h]
+    uint32_t nsub = 1, next_slot = 0;
     // profiling
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -278,10 +281,6 @@ int init_locked(int device) {
     g.msm_blocks_per_cu = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_msm_dma<EdMsm>, EdMsm::TB, msm_lds_bytes<EdMsm>()) == hipSuccess && occ > 0) g.msm_blocks_per_cu = occ;
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&g.start_ev, hipEventDisableTiming));
-    HIP_TRY(hipStreamCreateWithFlags(&g.side, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&g.side_go, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&g.side_done, hipEventDisableTiming));
     // generator tables (one-time, host)
     const size_t words = (size_t)NBASE * NWIN * SUBTAB_W;
     std::vector<uint32_t> tab(words);
@@ -306,10 +305,15 @@ int init_locked(int device) {
     g.max_chunks = g.p1.max_chunks > g.p2.max_chunks ? g.p1.max_chunks : g.p2.max_chunks;
     for (uint32_t r = 0; r < 6; r++) if (g.rd[r].max_chunks > g.max_chunks) g.max_chunks = g.rd[r].max_chunks;
     uint32_t ns = g_subbatches; if (ns < 1) ns = 1; if (ns > 8) ns = 8;
-    g.sub.resize(ns);
+    g.nsub = ns;
+    g.sub.resize((size_t)NSLOTS * ns);
     for (auto& sb : g.sub) {
         HIP_TRY(hipStreamCreateWithFlags(&sb.stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&sb.side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&sb.start, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sb.done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sb.side_go, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sb.side_done, hipEventDisableTiming));
     }
     g.ready = true;
     return 0;
@@ -397,18 +401,18 @@ int msm_and_encode(const LayoutSet& S, uint32_t rows, const uint32_t* digits, ui
 }
 
 // the whole prover for M jobs + C commitment tasks already described in the workspace
-int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st) {
+int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st, SubBatch& lane) {
     int rc;
     const dim3 gj((M + TB - 1) / TB), gw((M + TW - 1) / TW);
     // The commitment tasks (one small MSM, one inverse-square-root chain on C/64 waves) depend on nothing the proofs compute:
     // they go to a side stream and overlap the tape / first MSM instead of standing in front of them.
     const bool forked = C != 0 && M != 0;
     if (C) {
-        hipStream_t cs = forked ? g.side : st;
-        if (forked) { HIP_TRY(hipEventRecord(g.side_go, st)); HIP_TRY(hipStreamWaitEvent(cs, g.side_go, 0)); }
+        hipStream_t cs = forked ? lane.side : st;
+        if (forked) { HIP_TRY(hipEventRecord(lane.side_go, st)); HIP_TRY(hipStreamWaitEvent(cs, lane.side_go, 0)); }
         k_ctask<<<(C + TB - 1) / TB, TB, 0, cs>>>(w.T);
         if ((rc = msm_and_encode(g.ct, C, w.T.digits, w.ct_partial, w.ct_sums, w.ct_enc, w.ct_off, w.V.out, cs))) return rc;
-        if (forked) HIP_TRY(hipEventRecord(g.side_done, cs));
+        if (forked) HIP_TRY(hipEventRecord(lane.side_done, cs));
     }
     if (M == 0) { HIP_TRY(hipGetLastError()); return 0; }
     k_tape<<<dim3(gj.x, TAPE_SLOTS + 1), TB, 0, st>>>(w.V);
@@ -425,7 +429,7 @@ int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st) {
         if ((rc = msm_and_encode(g.rd[r], M, w.V.dr, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
         k_transcript_round<<<gw, TW, 0, st>>>(w.V, r);
     }
-    if (forked) HIP_TRY(hipStreamWaitEvent(st, g.side_done, 0));
+    if (forked) HIP_TRY(hipStreamWaitEvent(st, lane.side_done, 0));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -445,27 +449,29 @@ int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_
     if (n > (1u << 30)) return fail(ZKP_HIP_E_ARGUMENT, "batch too large");
     if (stride < RANGE_PROOF_BYTES) return fail(ZKP_HIP_E_ARGUMENT, "stride must be >= 1478");
     int rc;
-    uint32_t nsub = (uint32_t)g.sub.size();
+    uint32_t nsub = g.nsub;
     if (n < 512) nsub = 1;                       // small batches: one stream
     const uint64_t per = (n + nsub - 1) / nsub;
-    HIP_TRY(hipEventRecord(g.start_ev, st));
+    const uint32_t slot = g.next_slot; g.next_slot = (g.next_slot + 1) % NSLOTS;
+    SubBatch& first = g.sub[(size_t)slot * g.nsub];
+    HIP_TRY(hipEventRecord(first.start, st));
     for (uint32_t h = 0; h < nsub; h++) {
         const uint64_t lo = h * per, hi = (lo + per < n) ? lo + per : n;
         if (lo >= hi) continue;
-        SubBatch& sb = g.sub[h];
+        SubBatch& sb = g.sub[(size_t)slot * g.nsub + h];
         const uint32_t C = (uint32_t)(hi - lo), M = 2 * C;
         if ((rc = ensure_workspace(sb, M, C))) return rc;
         Ws w; carve((uint8_t*)sb.ws, M, C, g.max_chunks, &w);
         w.V.seeds = reinterpret_cast<const uint32_t*>(d_seeds + 32 * lo); w.T.seeds = w.V.seeds;
         w.V.out = d_out + lo * stride;
-        HIP_TRY(hipStreamWaitEvent(sb.stream, g.start_ev, 0));
+        HIP_TRY(hipStreamWaitEvent(sb.stream, first.start, 0));        // (the slot's previous batch is ahead of this one on sb.stream)
         k_build_range<<<(C + TB - 1) / TB, TB, 0, sb.stream>>>(w.J, C, d_value + lo, d_min + lo, d_max + lo, w.V.out, stride, d_out_len + lo, d_status + lo);
-        if ((rc = run_pipeline(w, M, C, sb.stream))) return rc;
-        HIP_TRY(hipEventRecord(sb.done, sb.stream));
+        if ((rc = run_pipeline(w, M, C, sb.stream, sb))) return rc;
+        HIP_TRY(hipEventRecord(sb.done, sb.stream)); sb.used = true;
         HIP_TRY(hipStreamWaitEvent(st, sb.done, 0));
     }
     if (any_failed) {
-        Ws w; carve((uint8_t*)g.sub[0].ws, g.sub[0].capM, g.sub[0].capC, g.max_chunks, &w);
+        Ws w; carve((uint8_t*)first.ws, first.capM, first.capC, g.max_chunks, &w);
         HIP_TRY(hipMemsetAsync(w.flag, 0, sizeof(int), st));
         k_any_failed<<<(uint32_t)((n + TB - 1) / TB), TB, 0, st>>>(d_status, (uint32_t)n, w.flag);
         HIP_TRY(hipMemcpyAsync(any_failed, w.flag, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -495,10 +501,11 @@ int run_host_jobs(const HostJobs& H, const uint8_t* seeds, size_t nseeds, uint8_
     if (M == 0 && C == 0) return 0;
     int rc;
     SubBatch& sb = g.sub[0];
+    hipStream_t st = g.stream;
+    if (sb.used) HIP_TRY(hipStreamWaitEvent(st, sb.done, 0));          // an asynchronous device-pointer call may still own this workspace
     if ((rc = ensure_workspace(sb, M ? M : 1, C ? C : 1))) return rc;
     Ws w; carve((uint8_t*)sb.ws, M ? M : 1, C ? C : 1, g.max_chunks, &w);
     w.V.M = M; w.T.C = C;
-    hipStream_t st = g.stream;
     uint8_t *d_seeds = nullptr, *d_out = nullptr;
     HIP_TRY(hipMalloc(&d_seeds, 32 * nseeds)); HIP_TRY(hipMalloc(&d_out, out_bytes));
     HIP_TRY(hipMemcpyAsync(d_seeds, seeds, 32 * nseeds, hipMemcpyHostToDevice, st));
@@ -509,7 +516,7 @@ int run_host_jobs(const HostJobs& H, const uint8_t* seeds, size_t nseeds, uint8_
     UP(w.J.ct_v, H.ct_v); UP(w.J.ct_seed_ix, H.ct_seed_ix); UP(w.J.ct_bl_ix, H.ct_bl_ix); UP(w.J.ct_off, H.ct_off);
 #undef UP
     w.V.seeds = reinterpret_cast<const uint32_t*>(d_seeds); w.T.seeds = w.V.seeds; w.V.out = d_out;
-    rc = run_pipeline(w, M, C, st);
+    rc = run_pipeline(w, M, C, st, sb);
     if (rc == 0) {
         HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -558,13 +565,14 @@ void zkp_hip_shutdown(void) {
     g16_release_all();
     bpv_release_all();
     if (g_stark_const) { (void)hipFree(g_stark_const); g_stark_const = nullptr; }
-    for (auto& sb : g.sub) { (void)hipFree(sb.ws); (void)hipStreamDestroy(sb.stream); (void)hipEventDestroy(sb.done); }
+    for (auto& sb : g.sub) {
+        (void)hipFree(sb.ws); (void)hipStreamDestroy(sb.stream); (void)hipStreamDestroy(sb.side);
+        (void)hipEventDestroy(sb.start); (void)hipEventDestroy(sb.done); (void)hipEventDestroy(sb.side_go); (void)hipEventDestroy(sb.side_done);
+    }
     (void)hipFree(g.d_table);
     free_set(g.p1); free_set(g.p2); free_set(g.ct);
     for (auto& d : g.rd) free_set(d);
     for (auto& e : g.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    (void)hipEventDestroy(g.start_ev);
-    (void)hipStreamDestroy(g.side); (void)hipEventDestroy(g.side_go); (void)hipEventDestroy(g.side_done);
     (void)hipStreamDestroy(g.stream);
     g = Ctx();
 }
