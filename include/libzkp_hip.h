@@ -109,6 +109,9 @@ int zkp_hip_verify_range_batch(uint64_t n, const uint8_t* proofs, uint64_t strid
  * one RangeProof per envelope (scheme 3) whose commitment must be C - threshold*B. */
 int zkp_hip_verify_threshold_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, const uint32_t* lens,
                                    const uint64_t* thresholds, uint8_t* ok);
+/* Same for proof::consistency_proof::verify_consistency(proof) (consistency_proof.rs:24-32 -> bulletproofs.rs:439-547):
+ * k commitments whose SHA-256 is the envelope commitment, k - 1 RangeProofs of the successive differences. */
+int zkp_hip_verify_consistency_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, const uint32_t* lens, uint8_t* ok);
 
 /* Replaces a loop of proof::improvement_proof::prove_improvement(old, new) (improvement_proof.rs:10-35 ->
  * StarkBackend::prove / prove_improvement, stark.rs:151-186,216-235; commitment utils/commitment.rs:38-50).

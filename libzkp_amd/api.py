@@ -404,6 +404,27 @@ def verify_threshold_batch(proofs, thresholds):
     return [bool(x) for x in ok]
 
 
+def verify_consistency_batch(proofs):
+    """Batched verify_consistency (consistency_proof.rs:24-32): list of bools."""
+    n = len(proofs)
+    if n == 0:
+        return []
+    blobs = [bytes(p) for p in proofs]
+    stride = min(1 << 20, max(16, max(len(b) for b in blobs)))
+    buf = np.zeros((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint32)
+    for i, b in enumerate(blobs):
+        lens[i] = len(b)
+        buf[i, : min(len(b), stride)] = np.frombuffer(b[:stride], dtype=np.uint8)
+    ok = np.zeros(n, dtype=np.uint8)
+    _native.check(_native.lib().zkp_hip_verify_consistency_batch(n, _P(buf), stride, _P(lens), _P(ok)), "zkp_hip_verify_consistency_batch")
+    return [bool(x) for x in ok]
+
+
+def verify_consistency(proof):
+    return verify_consistency_batch([proof])[0]
+
+
 def verify_improvement_batch(proofs, olds):
     """Batched verify_improvement (improvement_proof.rs:37-68): list of bools."""
     n = len(proofs)

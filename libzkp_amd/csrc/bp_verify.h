@@ -14,6 +14,7 @@
 // encoding is 32 zero bytes.
 #pragma once
 #include "bp_steps.h"
+#include "sha256_dev.h"
 
 namespace zkp {
 
@@ -35,6 +36,9 @@ struct VfyView {
     uint32_t* partial;            // the MSM partial array; proof-point products go to chunks var_chunk0 + p
     uint32_t var_chunk0;
     const uint32_t* table;        // generator tables (parse step: min*B, max*B)
+    // consistency proofs: a variable number of jobs per envelope
+    const uint32_t* job_base;     // [n + 1] first job of each envelope (host: k - 1 jobs where the framing can hold k commitments)
+    int32_t* env_bad;             // [n] envelope-level verdict of the framing / commitment checks
 };
 
 ZKP_HD inline void ld_bytes_words(uint32_t* w, const uint8_t* p, uint32_t nwords) {
@@ -181,6 +185,59 @@ ZKP_HD inline void step_vparse_threshold(const VfyView& V, uint32_t i, const uin
     V.proof_off[i] = env_off + 10 + 16; V.venc_off[i] = env_off + 10 + 16 + rl; V.bad[i] = 0;
 }
 
+// ---- step 0 for consistency proofs (consistency_proof.rs:24-32 + bulletproofs.rs:439-547): k commitments, k - 1 range
+// proofs of the successive differences, SHA-256 of the commitments as the envelope commitment.  thread = envelope
+ZKP_HD inline void step_vparse_consistency(const VfyView& V, uint32_t e, const uint8_t* env, uint64_t env_off, uint32_t len) {
+    const uint32_t jb = V.job_base[e], je = V.job_base[e + 1];
+    for (uint32_t j = jb; j < je; j++) { V.kind[j] = KIND_CONSISTENCY; V.proof_off[j] = 0; V.venc_off[j] = 0; V.bad[j] = 1; }
+    V.env_bad[e] = 1;
+    if (len < 10 || len > 1024u * 1024u || env[0] != 2 || env[1] != 6) return;
+    const uint32_t bl = ld_u32(env + 2), cl = ld_u32(env + 6);
+    if (bl > 900u * 1024u || cl != 32 || (uint64_t)10 + bl + cl != len) return;
+    const uint8_t* body = env + 10; const uint8_t* comm = env + 10 + bl;
+    if (bl < 4) return;
+    const uint32_t k = ld_u32(body);
+    uint64_t left = bl - 4, pos = 4;
+    if (k == 0 || left < 32ull * k || k - 1 != je - jb) return;
+    const uint8_t* commits = body + 4; pos += 32ull * k; left -= 32ull * k;
+    uint8_t dg[32]; sha256_bytes(dg, commits, 32ull * k);
+    for (int i = 0; i < 32; i++) if (dg[i] != comm[i]) return;
+    uint32_t w[8];
+    for (uint32_t i = 0; i < k; i++) { ge p; ld_bytes_words(w, commits + 32 * i, 8); if (!ge_ristretto_decode(p, w)) return; }
+    bool lens_ok = true;
+    for (uint32_t i = 1; i < k; i++) {
+        if (left < 4) return;
+        const uint32_t rl = ld_u32(body + pos); pos += 4; left -= 4;
+        if (left < rl) return;
+        V.proof_off[jb + i - 1] = env_off + 10 + pos; pos += rl; left -= rl;
+        lens_ok = lens_ok && rl == RP_BYTES;
+    }
+    ge prev; ld_bytes_words(w, commits, 8); (void)ge_ristretto_decode(prev, w);
+    for (uint32_t i = 1; i < k; i++) {
+        if (left < 32) return;
+        ge d, cur; uint32_t wd[8], e2[8];
+        ld_bytes_words(wd, body + pos, 8);
+        if (!ge_ristretto_decode(d, wd)) return;
+        ld_bytes_words(w, commits + 32 * i, 8); (void)ge_ristretto_decode(cur, w);
+        ge_ristretto_encode(e2, ge_add(cur, ge_neg(prev)));
+        for (int q = 0; q < 8; q++) if (e2[q] != wd[q]) return;
+        if (!lens_ok) return;                                   // verify_single rejects a proof of the wrong length (after these checks, as upstream orders them)
+        V.venc_off[jb + i - 1] = env_off + 10 + pos;
+        prev = cur; pos += 32; left -= 32;
+    }
+    V.env_bad[e] = 0;
+    for (uint32_t j = jb; j < je; j++) V.bad[j] = 0;
+}
+// verdict for a variable number of jobs per envelope
+ZKP_HD inline void step_vfinal_ranges(const VfyView& V, const uint32_t* enc, uint32_t e, uint8_t* ok) {
+    uint32_t verdict = V.env_bad[e] ? 0u : 1u;
+    for (uint32_t j = V.job_base[e]; j < V.job_base[e + 1]; j++) {
+        uint32_t o = 0; for (int q = 0; q < 8; q++) o |= enc[(size_t)q * V.M + j];
+        if (V.bad[j] || o != 0) verdict = 0;
+    }
+    ok[e] = (uint8_t)verdict;
+}
+
 // ---- step 1: decode the 17 points of a job.  thread = (p, job)
 ZKP_HD inline void step_vdecode(const VfyView& V, uint32_t p, uint32_t job) {
     if (V.bad[job]) return;
@@ -205,6 +262,7 @@ ZKP_HD inline void step_vtranscript(const VfyView& V, uint32_t job, Strobe& s) {
     switch (V.kind[job]) {
         case KIND_RANGE_MIN: merlin_init(s, "libzkp_range_min", 16); break;
         case KIND_RANGE_MAX: merlin_init(s, "libzkp_range_max", 16); break;
+        case KIND_CONSISTENCY: merlin_init(s, "libzkp_consistency", 18); break;
         default: merlin_init(s, "libzkp_threshold", 16); break;
     }
     merlin_append_bytes(s, "dom-sep", 7, "rangeproof v1", 13);

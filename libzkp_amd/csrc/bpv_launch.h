@@ -5,6 +5,8 @@
 
 void bpv_launch_parse(const zkp::VfyView& V, uint32_t n, uint64_t stride, const uint32_t* d_len, const uint64_t* d_min, const uint64_t* d_max, hipStream_t st);
 void bpv_launch_parse_threshold(const zkp::VfyView& V, uint32_t n, uint64_t stride, const uint32_t* d_len, const uint64_t* d_thr, hipStream_t st);
+void bpv_launch_parse_consistency(const zkp::VfyView& V, uint32_t n, uint64_t stride, const uint32_t* d_len, hipStream_t st);
+void bpv_launch_final_ranges(const zkp::VfyView& V, const uint32_t* d_enc, uint32_t n, uint8_t* d_ok, hipStream_t st);
 void bpv_launch_decode(const zkp::VfyView& V, hipStream_t st);
 void bpv_launch_transcript(const zkp::VfyView& V, hipStream_t st);
 void bpv_launch_scalars(const zkp::VfyView& V, hipStream_t st);

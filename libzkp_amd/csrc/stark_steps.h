@@ -9,6 +9,7 @@
 // see oracle/py/stark.py (the restatement this code is tested against, bit for bit).
 #pragma once
 #include "zkp_common.h"
+#include "sha256_dev.h"
 // The hash compression, the field product and the serial tail are real (non-inlined) device functions: the kernel is
 // latency-bound on lane 0's hash chain, not on call overhead, and full inlining made a 60k-instruction kernel that took
 // 12 minutes to compile.
@@ -142,40 +143,14 @@ ZKP_HD inline void blake3_elements(uint32_t out[8], const f128* e, uint32_t n) {
     blake3_words(out, w, 4 * n);
 }
 
-// ---------------------------------------------------------------------------------------------- SHA-256 of the 37-byte binding commitment
-ZKP_HD constexpr uint32_t sha256_k(int i) {
-    constexpr uint32_t K[64] = {
-        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
-        0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
-        0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
-        0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
-        0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
-        0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-    return K[i];
-}
-// SHA-256("libzkp_improvement_v1" || u64le(old) || u64le(new))  (utils/commitment.rs:38-50); one padded block
-ZKP_HD_NOINLINE inline void improvement_commitment(uint8_t out[32], uint64_t oldv, uint64_t newv) {
-    uint8_t blk[64];
+// ---------------------------------------------------------------------------------------------- the binding commitment
+// SHA-256("libzkp_improvement_v1" || u64le(old) || u64le(new))  (utils/commitment.rs:38-50)
+ZKP_HD inline void improvement_commitment(uint8_t out[32], uint64_t oldv, uint64_t newv) {
+    uint8_t msg[37];
     const char tag[22] = "libzkp_improvement_v1";
-    for (int i = 0; i < 21; i++) blk[i] = (uint8_t)tag[i];
-    for (int i = 0; i < 8; i++) { blk[21 + i] = (uint8_t)(oldv >> (8 * i)); blk[29 + i] = (uint8_t)(newv >> (8 * i)); }
-    blk[37] = 0x80; for (int i = 38; i < 64; i++) blk[i] = 0;
-    blk[62] = (uint8_t)((37 * 8) >> 8); blk[63] = (uint8_t)(37 * 8);
-    uint32_t w[64];
-    for (int i = 0; i < 16; i++) w[i] = ((uint32_t)blk[4 * i] << 24) | ((uint32_t)blk[4 * i + 1] << 16) | ((uint32_t)blk[4 * i + 2] << 8) | blk[4 * i + 3];
-    for (int i = 16; i < 64; i++) {
-        const uint32_t s0 = rotr32(w[i - 15], 7) ^ rotr32(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr32(w[i - 2], 17) ^ rotr32(w[i - 2], 19) ^ (w[i - 2] >> 10);
-        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
-    }
-    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
-    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-    for (int i = 0; i < 64; i++) {
-        const uint32_t t1 = hh + (rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25)) + ((e & f) ^ (~e & g)) + sha256_k(i) + w[i];
-        const uint32_t t2 = (rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
-        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-    }
-    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
-    for (int k = 0; k < 8; k++) { out[4 * k] = (uint8_t)(h[k] >> 24); out[4 * k + 1] = (uint8_t)(h[k] >> 16); out[4 * k + 2] = (uint8_t)(h[k] >> 8); out[4 * k + 3] = (uint8_t)h[k]; }
+    for (int i = 0; i < 21; i++) msg[i] = (uint8_t)tag[i];
+    for (int i = 0; i < 8; i++) { msg[21 + i] = (uint8_t)(oldv >> (8 * i)); msg[29 + i] = (uint8_t)(newv >> (8 * i)); }
+    sha256_bytes(out, msg, 37);
 }
 
 // ---------------------------------------------------------------------------------------------- the prover

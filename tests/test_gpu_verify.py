@@ -114,3 +114,29 @@ def test_threshold_verification_matches_oracle(hip, oracle_c):
     assert z.verify_threshold(proofs[3], ths[3]) and not z.verify_threshold(proofs[3][:-1], ths[3]) and not z.verify_threshold(b"", 0)
     # a range envelope is not a threshold envelope
     assert not z.verify_threshold(z.prove_range(5, 0, 10), 0)
+
+
+def test_consistency_verification_matches_oracle(hip, oracle_c):
+    import ctypes
+    import libzkp_amd as z
+    rng = np.random.default_rng(29)
+    data = []
+    for k in (1, 2, 2, 3, 5, 8, 1, 4):
+        data.append(sorted(int(x) for x in rng.integers(0, 2**50, k)))
+    data[2] = [7, 7]                                           # equal neighbours: difference 0
+    proofs = z.prove_consistency_batch(data, seeds=bytes(rng.integers(0, 256, 32 * len(data), dtype=np.uint8)))
+    orc = oracle_c
+    orc.zkp_oracle_verify_consistency.argtypes = [ctypes.c_char_p, ctypes.c_uint32]
+    assert all(orc.zkp_oracle_verify_consistency(p, len(p)) == 1 for p in proofs)
+    assert z.verify_consistency_batch(proofs) == [True] * len(proofs)
+    # tampering anywhere (header, count, commitments, proofs, difference commitments, digest): verdicts equal the oracle's
+    bad = []
+    for p in proofs:
+        for frac in (0.0, 0.01, 0.2, 0.5, 0.8, 0.97, 0.999):
+            b = bytearray(p); i = min(len(p) - 1, int(frac * len(p))); b[i] ^= 1 << int(rng.integers(0, 8)); bad.append(bytes(b))
+    want = [bool(orc.zkp_oracle_verify_consistency(b, len(b))) for b in bad]
+    assert z.verify_consistency_batch(bad) == want and not any(want)
+    assert not z.verify_consistency(b"") and not z.verify_consistency(proofs[4][:-1]) and not z.verify_consistency(proofs[0] + b"\\0")
+    # a proof for a different list does not transplant
+    sw = bytearray(proofs[3]); sw[14:46] = proofs[4][14:46]
+    assert z.verify_consistency(bytes(sw)) == bool(orc.zkp_oracle_verify_consistency(bytes(sw), len(sw))) is False
