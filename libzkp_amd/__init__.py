@@ -14,6 +14,10 @@ from .api import (  # noqa: F401
     process_batch, get_batch_status, clear_batch, benchmark_proof_generation, benchmark_proof_generation_numeric,
     ZkpBackendError,
 )
+from .composite import (  # noqa: F401
+    create_composite_proof, verify_composite_proof, verify_composite_proof_integrity_only, create_proof_with_metadata,
+    extract_proof_metadata, verify_proofs_parallel, validate_proof_chain, get_proof_info,
+)
 from ._native import NativeError  # noqa: F401
 
 __all__ = [
@@ -24,5 +28,7 @@ __all__ = [
     "create_proof_batch", "batch_add_range_proof", "batch_add_equality_proof",
     "batch_add_threshold_proof", "batch_add_membership_proof", "batch_add_improvement_proof", "batch_add_consistency_proof",
     "process_batch", "get_batch_status", "clear_batch", "benchmark_proof_generation", "benchmark_proof_generation_numeric",
+    "create_composite_proof", "verify_composite_proof", "verify_composite_proof_integrity_only", "create_proof_with_metadata",
+    "extract_proof_metadata", "verify_proofs_parallel", "validate_proof_chain", "get_proof_info",
     "NativeError", "ZkpBackendError",
 ]

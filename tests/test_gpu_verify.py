@@ -140,3 +140,25 @@ def test_consistency_verification_matches_oracle(hip, oracle_c):
     # a proof for a different list does not transplant
     sw = bytearray(proofs[3]); sw[14:46] = proofs[4][14:46]
     assert z.verify_consistency(bytes(sw)) == bool(orc.zkp_oracle_verify_consistency(bytes(sw), len(sw))) is False
+
+
+def test_composite_and_parallel_verification(hip):
+    """verify_composite_proof / verify_proofs_parallel (advanced/composite.rs:25-35, performance.rs:251-293) over the GPU verifiers"""
+    import libzkp_amd as z
+    r = z.prove_range(25, 18, 65)
+    t = z.prove_threshold([10, 20, 30], 50)
+    i = z.prove_improvement(30, 50)
+    k = z.prove_consistency([1, 5, 9])
+    comp = z.create_composite_proof([r, t, i, k])
+    assert z.verify_composite_proof_integrity_only(comp) and z.verify_composite_proof(comp)
+    meta = z.create_proof_with_metadata(r, {"purpose": b"age check"})
+    assert z.verify_composite_proof(meta) and z.extract_proof_metadata(meta) == {"purpose": b"age check"}
+    # an inner proof that is well-formed but cryptographically wrong: integrity passes, full verification does not
+    bad_r = bytearray(r); bad_r[700] ^= 1
+    comp_bad = z.create_composite_proof([bytes(bad_r), t])
+    assert z.verify_composite_proof_integrity_only(comp_bad) and not z.verify_composite_proof(comp_bad)
+    got = z.verify_proofs_parallel([(r, "range"), (t, "threshold"), (i, "improvement"), (k, "consistency"),
+                                    (r, "threshold"), (bytes(bad_r), "range"), (b"junk", "range"), (i, "nope")])
+    assert got == [True, True, True, True, False, False, False, False]
+    with pytest.raises(NotImplementedError):
+        z.verify_proofs_parallel([(bytes([2, 2]) + (256).to_bytes(4, "little") + (32).to_bytes(4, "little") + bytes(288), "equality")])
