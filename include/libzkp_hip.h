@@ -126,6 +126,14 @@ int zkp_hip_prove_improvement_batch(uint64_t n, const uint64_t* old_values, cons
 int zkp_hip_prove_improvement_batch_device(uint64_t n, const uint64_t* d_old, const uint64_t* d_new, uint8_t* d_out, uint64_t stride,
                                            uint32_t* d_out_len, void* stream);
 
+/* Groth16 verification of equality (scheme 2, 298 B) / membership (scheme 4) envelopes under the verifying key that leads
+ * the loaded proving key (zkp_hip_groth16_load_key / _generate_key): SnarkBackend::verify_equality_zk (snark.rs:377-401) and
+ * verify_membership_zk (snark.rs:455-495) as reached from verify_proof_cryptographic (proof_helpers.rs:180-206).  The public
+ * inputs are the envelope's own commitment (and embedded set); callers compare those with what they expect, as
+ * equality_proof.rs:34-60 / set_membership.rs:40-70 do.  ok[i] = 1 accepted / 0 rejected. */
+int zkp_hip_verify_equality_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, const uint32_t* lens, uint8_t* ok);
+int zkp_hip_verify_membership_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, const uint32_t* lens, uint8_t* ok);
+
 /* Replaces a loop of proof::improvement_proof::verify_improvement(proof, old) (improvement_proof.rs:37-68 ->
  * StarkBackend::verify, stark.rs:190-211,237-255): ok[i] = 1 accepted / 0 rejected (framing, stored old != old, binding
  * commitment, transcript-derived checks, Merkle openings, DEEP / remainder consistency). */

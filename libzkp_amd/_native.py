@@ -15,7 +15,8 @@ EXPORTS = (
     "zkp_hip_prove_range_batch_device", "zkp_hip_prove_threshold_batch", "zkp_hip_prove_consistency_batch",
     "zkp_hip_consistency_proof_bytes", "zkp_hip_groth16_load_key", "zkp_hip_groth16_generate_key", "zkp_hip_snark_commit_value_batch",
     "zkp_hip_prove_equality_batch", "zkp_hip_prove_membership_batch", "zkp_hip_improvement_max_bytes", "zkp_hip_prove_improvement_batch",
-    "zkp_hip_prove_improvement_batch_device", "zkp_hip_verify_range_batch", "zkp_hip_verify_threshold_batch", "zkp_hip_verify_consistency_batch", "zkp_hip_verify_improvement_batch", "zkp_hip_process_batch", "zkp_hip_profile_enable", "zkp_hip_profile_read", "zkp_hip_set_window_budget", "zkp_hip_set_subbatches", "zkp_hip_set_msm_variant",
+    "zkp_hip_prove_improvement_batch_device", "zkp_hip_verify_range_batch", "zkp_hip_verify_threshold_batch", "zkp_hip_verify_consistency_batch", "zkp_hip_verify_equality_batch", "zkp_hip_verify_membership_batch",
+    "zkp_hip_verify_improvement_batch", "zkp_hip_process_batch", "zkp_hip_profile_enable", "zkp_hip_profile_read", "zkp_hip_set_window_budget", "zkp_hip_set_subbatches", "zkp_hip_set_msm_variant",
 )
 
 _lib = None
@@ -93,6 +94,10 @@ def lib():
         L.zkp_hip_verify_threshold_batch.restype = ctypes.c_int
         L.zkp_hip_verify_consistency_batch.argtypes = [u64, vp, u64, vp, vp]
         L.zkp_hip_verify_consistency_batch.restype = ctypes.c_int
+        L.zkp_hip_verify_equality_batch.argtypes = [u64, vp, u64, vp, vp]
+        L.zkp_hip_verify_equality_batch.restype = ctypes.c_int
+        L.zkp_hip_verify_membership_batch.argtypes = [u64, vp, u64, vp, vp]
+        L.zkp_hip_verify_membership_batch.restype = ctypes.c_int
         L.zkp_hip_verify_improvement_batch.argtypes = [u64, vp, u64, vp, vp, vp]
         L.zkp_hip_verify_improvement_batch.restype = ctypes.c_int
         L.zkp_hip_process_batch.argtypes = [u64, vp, vp, vp, vp, u64, vp, vp]

@@ -404,6 +404,68 @@ def verify_threshold_batch(proofs, thresholds):
     return [bool(x) for x in ok]
 
 
+def _verify_snark_envelopes(kind, blobs):
+    """Groth16 pairing check of equality (kind 0) / membership (kind 1) envelopes under the loaded key; public inputs are the
+    envelope's own commitment and embedded set."""
+    n = len(blobs)
+    if n == 0:
+        return []
+    _ensure_key(kind)
+    stride = min(4096, max(16, max(len(b) for b in blobs)))
+    buf = np.zeros((n, stride), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint32)
+    for i, b in enumerate(blobs):
+        lens[i] = len(b)
+        buf[i, : min(len(b), stride)] = np.frombuffer(b[:stride], dtype=np.uint8)
+    ok = np.zeros(n, dtype=np.uint8)
+    fn = _native.lib().zkp_hip_verify_equality_batch if kind == 0 else _native.lib().zkp_hip_verify_membership_batch
+    _native.check(fn(n, _P(buf), stride, _P(lens), _P(ok)), "zkp_hip_verify_%s_batch" % ("equality" if kind == 0 else "membership"))
+    return [bool(x) for x in ok]
+
+
+def verify_equality_with_commitment_batch(proofs, commitments):
+    """Batched verify_equality_with_commitment (equality_proof.rs:34-60): the envelope must carry exactly that commitment."""
+    blobs = [bytes(p) for p in proofs]
+    cms = [bytes(c) for c in commitments]
+    if len(cms) != len(blobs):
+        raise ValueError("proofs, commitments must have equal length")
+    crypto = _verify_snark_envelopes(0, blobs)
+    return [ok and len(c) == 32 and len(b) == 298 and b[266:] == c for ok, b, c in zip(crypto, blobs, cms)]
+
+
+def verify_equality_with_commitment(proof, commitment):
+    return verify_equality_with_commitment_batch([proof], [commitment])[0]
+
+
+def verify_equality(proof, val1, val2):
+    """equality_proof.rs:52-59"""
+    val1, val2 = _check_u64("val1", val1), _check_u64("val2", val2)
+    if val1 != val2:
+        return False
+    return verify_equality_with_commitment(proof, snark_commit_value(val1))
+
+
+def verify_membership_batch(proofs, sets):
+    """Batched verify_membership (set_membership.rs:40-70): the embedded set must equal `set` as a multiset."""
+    blobs = [bytes(p) for p in proofs]
+    if len(sets) != len(blobs):
+        raise ValueError("proofs, sets must have equal length")
+    crypto = _verify_snark_envelopes(1, blobs)
+    out = []
+    for ok, b, st in zip(crypto, blobs, sets):
+        good = ok and len(b) >= 14
+        if good:
+            n = int.from_bytes(b[10:14], "little")
+            emb = [int.from_bytes(b[14 + 8 * i: 22 + 8 * i], "little") for i in range(n)] if len(b) == 10 + 4 + 8 * n + 256 + 32 else None
+            good = emb is not None and sorted(emb) == sorted(_check_u64("set element", x) for x in st)
+        out.append(bool(good))
+    return out
+
+
+def verify_membership(proof, set):  # noqa: A002
+    return verify_membership_batch([proof], [list(set)])[0]
+
+
 def verify_consistency_batch(proofs):
     """Batched verify_consistency (consistency_proof.rs:24-32): list of bools."""
     n = len(proofs)

@@ -9,8 +9,7 @@
                                     /root/reference/src/utils/performance.rs:251-293, utils/proof_helpers.rs:156-247
 
 Pure host-side framing (SHA-256, length-prefixed fields) around proofs that the GPU produces and verifies; the
-cryptographic checks go through libzkp_amd.api's batched GPU verifiers.  Groth16 (pairing) verification is not built
-on the GPU: envelopes of scheme 2 / 4 make the cryptographic calls raise NotImplementedError instead of guessing.
+cryptographic checks go through libzkp_amd.api's batched GPU verifiers (Bulletproofs family, STARK, Groth16 pairing check).
 Error mapping as in api.py: InvalidInput -> ValueError, InvalidProofFormat -> TypeError (error_handling.rs:39-50)."""
 import hashlib
 
@@ -140,7 +139,7 @@ def verify_proof_cryptographic_batch(envelopes):
     """verify_proof_cryptographic for a list of envelopes, one batched GPU call per scheme (proof_helpers.rs:156-247)."""
     from . import api
     out = [False] * len(envelopes)
-    groups = {1: [], 3: [], 5: [], 6: []}
+    groups = {1: [], 2: [], 3: [], 4: [], 5: [], 6: []}
     for i, env in enumerate(envelopes):
         try:
             version, scheme, payload, commitment = parse_proof(env)
@@ -148,9 +147,11 @@ def verify_proof_cryptographic_batch(envelopes):
             continue
         if version != PROOF_VERSION:
             continue
-        if scheme in (2, 4):
-            raise NotImplementedError("Groth16 (pairing) verification is not built on the HIP backend (schemes 2 and 4)")
-        if scheme == 1 and len(payload) >= 20 and len(commitment) == 32:
+        if scheme == 2 and len(commitment) == 32:
+            groups[2].append((i, env))
+        elif scheme == 4 and len(commitment) == 32 and len(payload) > 4:
+            groups[4].append((i, env))
+        elif scheme == 1 and len(payload) >= 20 and len(commitment) == 32:
             mn, mx = int.from_bytes(payload[:8], "little"), int.from_bytes(payload[8:16], "little")
             if mn <= mx:
                 groups[1].append((i, env, mn, mx))
@@ -162,6 +163,12 @@ def verify_proof_cryptographic_batch(envelopes):
             groups[6].append((i, env))
     if groups[1]:
         for (i, *_), ok in zip(groups[1], api.verify_range_batch([g[1] for g in groups[1]], [g[2] for g in groups[1]], [g[3] for g in groups[1]])):
+            out[i] = ok
+    if groups[2]:
+        for (i, *_), ok in zip(groups[2], api._verify_snark_envelopes(0, [g[1] for g in groups[2]])):
+            out[i] = ok
+    if groups[4]:
+        for (i, *_), ok in zip(groups[4], api._verify_snark_envelopes(1, [g[1] for g in groups[4]])):
             out[i] = ok
     if groups[3]:
         for (i, *_), ok in zip(groups[3], api.verify_threshold_batch([g[1] for g in groups[3]], [g[2] for g in groups[3]])):

@@ -1,0 +1,118 @@
+// Groth16 verification of libzkp's equality / membership envelopes:
+// SnarkBackend::verify_equality_zk (/root/reference/src/backend/snark.rs:377-401) and verify_membership_zk (:455-495),
+// i.e. ark-groth16's  e(A, B) == e(alpha, beta) e(sum x_i IC_i, gamma) e(C, delta)  with the public-input order of
+// snark.rs:397-398,482-492.  One thread verifies one envelope (pairing: bn254_pairing.h); restated in
+// oracle/py/groth16.py: verify / verify_equality_with_commitment / verify_membership.
+#pragma once
+#include "bn254_pairing.h"
+#include "g16_steps.h"
+
+namespace zkp {
+
+// verifying key in device memory (built by the host from the loaded proving key, which starts with the vk)
+struct G16Vk {
+    g2_aff gamma, delta;
+    fq12 ml_alpha_beta;            // Miller loop value of (beta, -alpha): the constant factor of the check
+    uint32_t n_ic;                 // gamma_abc_g1 length (1 + public inputs)
+    const uint32_t* ic;            // [n_ic][20] affine points, Montgomery limbs
+};
+
+ZKP_HD inline uint32_t ld_u32_le(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+ZKP_HD inline void ld_le_words(uint32_t w[8], const uint8_t* p) {
+    for (int i = 0; i < 8; i++) w[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+}
+ZKP_HD inline bool fq_raw_lt_p(const uint32_t w[8]) {
+    for (int i = 7; i >= 0; i--) { if (w[i] < FqParams::mod(i)) return true; if (w[i] > FqParams::mod(i)) return false; }
+    return false;
+}
+ZKP_HD inline bool fr_raw_lt_r(const uint32_t w[8]) {
+    for (int i = 7; i >= 0; i--) { if (w[i] < FrParams::mod(i)) return true; if (w[i] > FrParams::mod(i)) return false; }
+    return false;
+}
+// ark-serialize uncompressed G1: x || y little-endian, flags in the top two bits of the last byte (bn254_g.h: g1_serialize).
+// Returns 0 invalid, 1 finite point, 2 point at infinity.
+ZKP_HD_NOINLINE inline int g1_from_ark(g1_aff& out, const uint8_t b[64]) {
+    const uint32_t flags = b[63] & 0xC0u;
+    if (flags & 0x40u) return 2;
+    uint32_t xw[8], yw[8];
+    ld_le_words(xw, b); ld_le_words(yw, b + 32); yw[7] &= 0x3FFFFFFFu;
+    if (!fq_raw_lt_p(xw) || !fq_raw_lt_p(yw)) return 0;
+    out.x = fq_from_raw(xw); out.y = fq_from_raw(yw);
+    const fq rhs = fq_add(fq_mul(fq_sq(out.x), out.x), fq_from_u64(3));
+    if (!fq_eq(fq_sq(out.y), rhs)) return 0;
+    if (((flags & 0x80u) != 0) != fq_raw_gt_half(yw)) return 0;
+    return 1;
+}
+ZKP_HD_NOINLINE inline int g2_from_ark(g2_aff& out, const uint8_t b[128]) {
+    const uint32_t flags = b[127] & 0xC0u;
+    if (flags & 0x40u) return 2;
+    uint32_t w[4][8];
+    for (int k = 0; k < 4; k++) ld_le_words(w[k], b + 32 * k);
+    w[3][7] &= 0x3FFFFFFFu;
+    for (int k = 0; k < 4; k++) if (!fq_raw_lt_p(w[k])) return 0;
+    out.x = fq2{fq_from_raw(w[0]), fq_from_raw(w[1])}; out.y = fq2{fq_from_raw(w[2]), fq_from_raw(w[3])};
+    const fq2 b2 = f_mul(fq2{fq_from_u64(3), fq_zero()}, f_inv(fq2{fq_from_u64(9), fq_from_u64(1)}));       // 3 / (9 + u)
+    if (!fq2_eq(f_sq(out.y), f_add(f_mul(f_sq(out.x), out.x), b2))) return 0;
+    uint32_t nz = 0; for (int i = 0; i < 8; i++) nz |= w[3][i];
+    const bool larger = nz ? fq_raw_gt_half(w[3]) : fq_raw_gt_half(w[2]);
+    if (((flags & 0x80u) != 0) != larger) return 0;
+    // subgroup check: G2 has a cofactor, r * Q must be the identity
+    uint32_t rw[8]; for (int i = 0; i < 8; i++) rw[i] = FrParams::mod(i);
+    if (!jac_is_inf(jac_mul_raw(jac_from_aff(out), rw))) return 0;
+    return 1;
+}
+// k * P for a 64-bit scalar (set elements)
+ZKP_HD inline g1_jac g1_mul_u64(const g1_aff& p, uint64_t k) {
+    g1_jac acc = jac_infinity<fq>();
+    for (int i = 63; i >= 0; i--) {
+        acc = jac_dbl(acc);
+        if ((k >> i) & 1u) acc = jac_madd(acc, p);
+    }
+    return acc;
+}
+ZKP_HD inline g1_aff ld_ic(const G16Vk& vk, uint32_t i) {
+    g1_aff p; const uint32_t* q = vk.ic + (size_t)i * 20;
+    for (int k = 0; k < 10; k++) { p.x.v[k] = q[k]; p.y.v[k] = q[10 + k]; }
+    return p;
+}
+// the pairing check for proof bytes (A || B || C) and the accumulated public-input point L (Jacobian)
+ZKP_HD_NOINLINE inline bool g16_check(const G16Vk& vk, const uint8_t proof[256], const g1_jac& L) {
+    g1_aff A, C; g2_aff B;
+    const int ra = g1_from_ark(A, proof), rb = g2_from_ark(B, proof + 64), rc = g1_from_ark(C, proof + 192);
+    if (ra == 0 || rb == 0 || rc == 0) return false;
+    fq12 f = vk.ml_alpha_beta;
+    if (ra == 1 && rb == 1) f = fq12_mul(f, miller_loop(B, A));
+    g1_aff La;
+    if (jac_to_aff(La, L)) f = fq12_mul(f, miller_loop(vk.gamma, aff_neg(La)));
+    if (rc == 1) f = fq12_mul(f, miller_loop(vk.delta, aff_neg(C)));
+    return fq12_is_one(final_exponentiation(f));
+}
+// equality envelope (scheme 2, 298 bytes): public input = the embedded 32-byte commitment as an integer < r
+ZKP_HD_NOINLINE inline bool g16_verify_equality_envelope(const G16Vk& vk, const uint8_t* env, uint32_t len) {
+    if (len != 298 || env[0] != 2 || env[1] != 2 || vk.n_ic != 2) return false;
+    if (ld_u32_le(env + 2) != 256 || ld_u32_le(env + 6) != 32) return false;
+    uint32_t c[8]; ld_le_words(c, env + 266);
+    if (!fr_raw_lt_r(c)) return false;
+    const g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), jac_mul_raw(jac_from_aff(ld_ic(vk, 1)), c));
+    return g16_check(vk, env + 10, L);
+}
+// membership envelope (scheme 4): payload = u32 n || n x u64 set || 256-byte proof; public inputs =
+// commitment, 64 set slots (zero padded), 64 is_real flags (snark.rs:482-492)
+ZKP_HD_NOINLINE inline bool g16_verify_membership_envelope(const G16Vk& vk, const uint8_t* env, uint32_t len) {
+    if (len < 10 + 4 + 256 + 32 || env[0] != 2 || env[1] != 4 || vk.n_ic != 2 + 2 * G16_MAX_SET) return false;
+    const uint32_t plen = ld_u32_le(env + 2), clen = ld_u32_le(env + 6);
+    if (clen != 32 || (uint64_t)10 + plen + clen != len || plen < 4 + 256) return false;
+    const uint32_t n = ld_u32_le(env + 10);
+    if (n > G16_MAX_SET || plen != 4 + 8 * n + 256) return false;
+    uint32_t c[8]; ld_le_words(c, env + 10 + plen);
+    if (!fr_raw_lt_r(c)) return false;
+    g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), jac_mul_raw(jac_from_aff(ld_ic(vk, 1)), c));
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t v = 0; for (int k = 0; k < 8; k++) v |= (uint64_t)env[14 + 8 * i + k] << (8 * k);
+        if (v) L = jac_add(L, g1_mul_u64(ld_ic(vk, 2 + i), v));
+        L = jac_madd(L, ld_ic(vk, 2 + G16_MAX_SET + i));            // is_real = 1
+    }
+    return g16_check(vk, env + 14 + 8 * n, L);
+}
+
+}  // namespace zkp

@@ -22,6 +22,7 @@
 #include "g16_circuit.h"
 #include "msm_kernel.h"
 #include "g16_launch.h"
+#include "g16_verify_launch.h"
 #include "stark_launch.h"
 #include "bpv_launch.h"
 #include "../../include/libzkp_hip.h"

@@ -398,6 +398,8 @@ def prove_equality(val1, val2, setup_seed, seed):
 def verify_equality_with_commitment(proof_env, commitment, setup_seed):
     if len(proof_env) != 298 or proof_env[:2] != bytes([2, 2]) or proof_env[10 + 256:] != commitment:
         return False
+    if int.from_bytes(proof_env[2:6], "little") != 256 or int.from_bytes(proof_env[6:10], "little") != 32:     # Proof::from_bytes (proof/mod.rs:58-76)
+        return False
     c = int.from_bytes(commitment, "little")
     if c >= R:
         return False
@@ -431,6 +433,8 @@ def prove_membership(value, the_set, setup_seed, seed):
 def verify_membership(proof_env, the_set, setup_seed):
     n = len(the_set)
     if proof_env[:2] != bytes([2, 4]) or len(proof_env) != 10 + 4 + 8 * n + 256 + 32:
+        return False
+    if int.from_bytes(proof_env[2:6], "little") != 4 + 8 * n + 256 or int.from_bytes(proof_env[6:10], "little") != 32:
         return False
     payload, commitment = proof_env[10:-32], proof_env[-32:]
     if int.from_bytes(payload[:4], "little") != n or payload[4: 4 + 8 * n] != b"".join(x.to_bytes(8, "little") for x in the_set):

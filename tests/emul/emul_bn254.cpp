@@ -1,5 +1,5 @@
 // TEST INFRASTRUCTURE: host build of the BN254 device headers for the no-GPU test tier.
-#include "../../libzkp_amd/csrc/bn254_g.h"
+#include "../../libzkp_amd/csrc/bn254_pairing.h"
 #include <string.h>
 using namespace zkp;
 
@@ -73,5 +73,33 @@ void emul_g2_madd_chain(const uint32_t p[32], const int* signs, int n, uint32_t 
     g2_aff P = load_g2(p); g2_jac acc = jac_infinity<fq2>();
     for (int i = 0; i < n; i++) acc = jac_madd(acc, signs[i] < 0 ? aff_neg(P) : P);
     g2_serialize(out, acc);
+}
+
+// Fq12 product; operands and result as 12 canonical coefficients of oracle/py/bn254.py's basis Fq[w]/(w^12 - 18 w^6 + 82)
+static fq12 f12_from_poly(const uint32_t* c) {
+    fq2 k[6];
+    for (int i = 0; i < 6; i++) {
+        const fq lo = fq_from_raw(c + 8 * i), hi = fq_from_raw(c + 8 * (i + 6));
+        fq nine_hi = hi; for (int t = 0; t < 3; t++) nine_hi = fq_dbl(nine_hi); nine_hi = fq_add(nine_hi, hi);
+        k[i] = fq2{fq_add(lo, nine_hi), hi};
+    }
+    return fq12{fq6{k[0], k[2], k[4]}, fq6{k[1], k[3], k[5]}};
+}
+static void f12_to_poly(uint32_t* c, const fq12& a) {
+    const fq2 k[6] = {a.c0.a0, a.c1.a0, a.c0.a1, a.c1.a1, a.c0.a2, a.c1.a2};
+    for (int i = 0; i < 6; i++) {
+        fq nine = k[i].c1; for (int t = 0; t < 3; t++) nine = fq_dbl(nine); nine = fq_add(nine, k[i].c1);
+        fq_to_raw(c + 8 * i, fq_sub(k[i].c0, nine)); fq_to_raw(c + 8 * (i + 6), k[i].c1);
+    }
+}
+void emul_f12_mul(const uint32_t a[96], const uint32_t b[96], int square, uint32_t out[96]) {
+    const fq12 x = f12_from_poly(a), y = f12_from_poly(b);
+    f12_to_poly(out, square ? fq12_sq(x) : fq12_mul(x, y));
+}
+// prod_i ate(Q_i, P_i) == 1 ?  points as raw affine coordinates (16 / 32 words each)
+int emul_pairing_product_is_one(int n, const uint32_t* g1s, const uint32_t* g2s) {
+    fq12 f = fq12_one();
+    for (int i = 0; i < n; i++) f = fq12_mul(f, miller_loop(load_g2(g2s + 32 * i), load_g1(g1s + 16 * i)));
+    return fq12_is_one(final_exponentiation(f)) ? 1 : 0;
 }
 }

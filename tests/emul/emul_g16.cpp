@@ -1,6 +1,8 @@
 // TEST INFRASTRUCTURE: host run of the Groth16 witness + QAP steps (the per-proof work before the MSMs) so the no-GPU
 // tier can compare the full assignment z and the quotient coefficients h with the oracle.
 #include "../../libzkp_amd/csrc/g16_circuit.h"
+#include "../../libzkp_amd/csrc/g16_verify.h"
+#include <vector>
 using namespace zkp;
 
 struct NoSync { void operator()() const {} };
@@ -48,5 +50,18 @@ int emul_g16_witness_qap(int kind, uint64_t value, const uint64_t* set_vals, uin
     memcpy(rs_raw, rs.data(), 64);
     shape[0] = T.n_inst; shape[1] = T.n_wit; shape[2] = T.n_rows; shape[3] = T.m;
     return 0;
+}
+
+// Groth16 verification of one envelope (kind 0 equality / 1 membership) under a verifying key given as raw affine
+// coordinates: alpha (16 words), beta / gamma / delta (32 each), ic (n_ic x 16)
+int emul_g16_verify(int kind, const uint8_t* env, uint32_t len, const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma, const uint32_t* delta,
+                    uint32_t n_ic, const uint32_t* ic) {
+    auto g1 = [](const uint32_t* w) { return g1_aff{fq_from_raw(w), fq_from_raw(w + 8)}; };
+    auto g2 = [](const uint32_t* w) { return g2_aff{fq2{fq_from_raw(w), fq_from_raw(w + 8)}, fq2{fq_from_raw(w + 16), fq_from_raw(w + 24)}}; };
+    std::vector<uint32_t> icm((size_t)n_ic * 20);
+    for (uint32_t i = 0; i < n_ic; i++) { const g1_aff p = g1(ic + 16 * i); for (int k = 0; k < 10; k++) { icm[20 * i + k] = p.x.v[k]; icm[20 * i + 10 + k] = p.y.v[k]; } }
+    G16Vk vk; vk.gamma = g2(gamma); vk.delta = g2(delta); vk.n_ic = n_ic; vk.ic = icm.data();
+    vk.ml_alpha_beta = miller_loop(g2(beta), aff_neg(g1(alpha)));
+    return (kind == 0 ? g16_verify_equality_envelope(vk, env, len) : g16_verify_membership_envelope(vk, env, len)) ? 1 : 0;
 }
 }

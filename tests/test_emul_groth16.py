@@ -144,3 +144,80 @@ def test_witness_and_quotient_equal_oracle(libs):
         n = len(the_set)
         assert out[:2] == bytes([2, 4]) and out[10:14] == n.to_bytes(4, "little")
         assert out[14:14 + 8 * n] == b"".join(x.to_bytes(8, "little") for x in the_set)
+
+
+def _vk_args(pk):
+    g1w = lambda pt: [(pt[0] >> (32 * i)) & 0xFFFFFFFF for i in range(8)] + [(pt[1] >> (32 * i)) & 0xFFFFFFFF for i in range(8)]  # noqa: E731
+
+    def g2w(pt):
+        ws = []
+        for v in (pt[0][0], pt[0][1], pt[1][0], pt[1][1]):
+            ws += [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        return ws
+    A = lambda ws: (ctypes.c_uint32 * len(ws))(*ws)  # noqa: E731
+    ic = sum((g1w(p) for p in pk.gamma_abc_g1), [])
+    return A(g1w(pk.alpha_g1)), A(g2w(pk.beta_g2)), A(g2w(pk.gamma_g2)), A(g2w(pk.delta_g2)), len(pk.gamma_abc_g1), A(ic)
+
+
+def test_tower_and_pairing(libs):
+    """Fq12 tower arithmetic against the oracle's polynomial-basis Fq12, and bilinearity / non-degeneracy of the ate pairing."""
+    lib, _ = libs
+    rnd = random.Random(3)
+    W12 = lambda a: (ctypes.c_uint32 * 96)(*[(c >> (32 * i)) & 0xFFFFFFFF for c in a for i in range(8)])  # noqa: E731
+    I12 = lambda w: [sum(int(w[8 * k + i]) << (32 * i) for i in range(8)) for k in range(12)]  # noqa: E731
+    out = (ctypes.c_uint32 * 96)()
+    for _ in range(10):
+        x, y = [rnd.randrange(b.P) for _ in range(12)], [rnd.randrange(b.P) for _ in range(12)]
+        lib.emul_f12_mul(W12(x), W12(y), 0, out)
+        assert I12(out) == b.f12_mul(x, y)
+        lib.emul_f12_mul(W12(x), W12(y), 1, out)
+        assert I12(out) == b.f12_mul(x, x)
+    g1w = lambda pt: [(pt[0] >> (32 * i)) & 0xFFFFFFFF for i in range(8)] + [(pt[1] >> (32 * i)) & 0xFFFFFFFF for i in range(8)]  # noqa: E731
+
+    def g2w(pt):
+        ws = []
+        for v in (pt[0][0], pt[0][1], pt[1][0], pt[1][1]):
+            ws += [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+        return ws
+
+    def check(pairs):
+        g1 = (ctypes.c_uint32 * (16 * len(pairs)))(*sum((g1w(p) for p, q in pairs), []))
+        g2 = (ctypes.c_uint32 * (32 * len(pairs)))(*sum((g2w(q) for p, q in pairs), []))
+        return lib.emul_pairing_product_is_one(len(pairs), g1, g2)
+    a = rnd.randrange(1, b.R)
+    Pp, Q = b.G1C.mul_pt(b.G1, rnd.randrange(1, b.R)), b.G2C.mul_pt(b.G2, rnd.randrange(1, b.R))
+    aP, aQ, nP = b.G1C.mul_pt(Pp, a), b.G2C.mul_pt(Q, a), b.G1C.neg_pt(Pp)
+    assert check([(aP, Q), (nP, aQ)]) == 1                      # e(aP, Q) e(-P, aQ) = 1
+    assert check([(aP, Q), (nP, b.G2C.mul_pt(Q, a + 1))]) == 0
+    assert check([(Pp, Q)]) == 0                                # non-degenerate
+
+
+def test_groth16_verifier_verdicts_equal_oracle(libs):
+    """g16_verify.h (the GPU verifier's code, on the host) against the oracle's pairing verifier: valid proofs and a
+    flipped bit in every region of equality and membership envelopes."""
+    _, lib = libs
+    SS = bytes(range(32))
+    rnd = random.Random(1)
+    seed = bytes(range(7, 39))
+    r_, s_ = g.draw_fr(seed, 0x47313600, 0), g.draw_fr(seed, 0x47313600, 1)
+    pk = g.equality_key(SS)
+    va = _vk_args(pk)
+    v = 123456789
+    cm = g.commit_value_snark(v)
+    env = g.envelope(2, g.prove_with_trapdoor(pk, g.equality_circuit(v, v, int.from_bytes(cm, "little")), r_, s_), cm)
+    assert lib.emul_g16_verify(0, env, len(env), *va) == 1 and g.verify_equality_with_commitment(env, cm, SS)
+    for pos in (1, 5, 12, 80, 150, 210, 265, 270, 297):
+        bad = bytearray(env); bad[pos] ^= 1 << rnd.randrange(8)
+        assert bool(lib.emul_g16_verify(0, bytes(bad), len(bad), *va)) == g.verify_equality_with_commitment(bytes(bad), bytes(bad[266:]), SS) is False
+    assert lib.emul_g16_verify(0, env[:-1], len(env) - 1, *va) == 0
+    # membership
+    pkm = g.membership_key(SS)
+    vm = _vk_args(pkm)
+    the_set = [10, 20, 25, 30, 2**40]
+    envm = g.prove_membership(25, the_set, SS, seed)
+    assert lib.emul_g16_verify(1, envm, len(envm), *vm) == 1 and g.verify_membership(envm, the_set, SS)
+    for pos in (3, 11, 16, 30, 60, 200, 300, len(envm) - 5):
+        bad = bytearray(envm); bad[pos] ^= 1 << rnd.randrange(8)
+        n = int.from_bytes(bad[10:14], "little")
+        emb = [int.from_bytes(bad[14 + 8 * i:22 + 8 * i], "little") for i in range(n)] if 0 < n <= 64 and len(bad) == 10 + 4 + 8 * n + 288 else the_set
+        assert bool(lib.emul_g16_verify(1, bytes(bad), len(bad), *vm)) == g.verify_membership(bytes(bad), emb, SS) is False, pos

@@ -160,5 +160,41 @@ def test_composite_and_parallel_verification(hip):
     got = z.verify_proofs_parallel([(r, "range"), (t, "threshold"), (i, "improvement"), (k, "consistency"),
                                     (r, "threshold"), (bytes(bad_r), "range"), (b"junk", "range"), (i, "nope")])
     assert got == [True, True, True, True, False, False, False, False]
-    with pytest.raises(NotImplementedError):
-        z.verify_proofs_parallel([(bytes([2, 2]) + (256).to_bytes(4, "little") + (32).to_bytes(4, "little") + bytes(288), "equality")])
+
+
+def test_groth16_verification(hip):
+    """verify_equality / verify_membership (pairing check on the GPU) against the oracle's verifier; keys = the committed test keys"""
+    import os
+    import libzkp_amd as z
+    import libzkp_amd.api as api
+    from libzkp_amd import _native
+    from oracle.py import groth16 as g
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")):
+        api.install_proving_key(kind, open(os.path.join(gold, name), "rb").read())
+    SS = bytes(range(32))
+    rng = np.random.default_rng(31)
+    vals = [int(x) for x in rng.integers(0, 2**63, 24, dtype=np.uint64)]
+    seeds = bytes(rng.integers(0, 256, 32 * 24, dtype=np.uint8))
+    proofs = z.prove_equality_batch(vals, vals, seeds=seeds)
+    assert all(z.verify_equality(p, v, v) for p, v in zip(proofs[:4], vals[:4]))
+    assert z.verify_equality_with_commitment_batch(proofs, [z.snark_commit_value(v) for v in vals]) == [True] * 24
+    assert not z.verify_equality(proofs[0], vals[0], vals[0] + 1) and not z.verify_equality(proofs[0], vals[1], vals[1])
+    bad = []
+    for p in proofs:
+        b = bytearray(p); b[int(rng.integers(0, 298))] ^= 1 << int(rng.integers(0, 8)); bad.append(bytes(b))
+    want = [g.verify_equality_with_commitment(b, b[266:], SS) for b in bad[:8]]
+    got = api._verify_snark_envelopes(0, bad)
+    assert got[:8] == want and not any(got)
+    sets = [[int(x) for x in rng.choice(2**32, 5, replace=False)] for _ in range(6)]
+    mp = z.prove_membership_batch([s[i % 5] for i, s in enumerate(sets)], sets, seeds=seeds[:32 * 6])
+    assert z.verify_membership_batch(mp, sets) == [True] * 6
+    assert z.verify_membership(mp[0], list(reversed(sets[0]))) and not z.verify_membership(mp[0], sets[1])
+    assert g.verify_membership(mp[2], sets[2], SS)
+    b = bytearray(mp[3]); b[40] ^= 4
+    assert not z.verify_membership(bytes(b), sets[3])
+    # the composite / parallel front ends now cover all six schemes
+    r = z.prove_range(25, 18, 65)
+    comp = z.create_composite_proof([r, proofs[0], mp[0]])
+    assert z.verify_composite_proof(comp)
+    assert z.verify_proofs_parallel([(proofs[1], "equality"), (mp[1], "membership"), (bad[1], "equality"), (proofs[2], "membership")]) == [True, True, False, False]
