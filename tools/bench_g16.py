@@ -27,3 +27,8 @@ else:
 for it in range(4):
     t0=time.time(); rc=call(); dt=time.time()-t0
     print(kind,"n",n,"rc",rc,"%.1f ms -> %.0f proofs/s"%(dt*1e3,n/dt), "ok" if (st==0).all() else "FAIL")
+if kind == "equality":
+    ok = np.zeros(n, dtype=np.uint8)
+    for it in range(2):
+        t0 = time.time(); rc = L.zkp_hip_verify_equality_batch(n, P(o), 298, P(ln), P(ok)); dt = time.time() - t0
+        print("verify equality n", n, "rc", rc, "%.1f ms -> %.0f envelopes/s" % (dt * 1e3, n / dt), "all ok" if (ok == 1).all() else "FAIL")
