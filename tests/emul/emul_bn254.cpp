@@ -97,6 +97,9 @@ void emul_f12_mul(const uint32_t a[96], const uint32_t b[96], int square, uint32
     f12_to_poly(out, square ? fq12_sq(x) : fq12_mul(x, y));
 }
 // prod_i ate(Q_i, P_i) == 1 ?  points as raw affine coordinates (16 / 32 words each)
+// final exponentiation two ways (easy/hard split vs one 2790-bit power) and the Fq12 inverse, in the oracle's basis
+void emul_f12_final_exp(const uint32_t a[96], int naive, uint32_t out[96]) { f12_to_poly(out, naive ? final_exponentiation_naive(f12_from_poly(a)) : final_exponentiation(f12_from_poly(a))); }
+void emul_f12_inv(const uint32_t a[96], uint32_t out[96]) { f12_to_poly(out, fq12_inv(f12_from_poly(a))); }
 int emul_pairing_product_is_one(int n, const uint32_t* g1s, const uint32_t* g2s) {
     fq12 f = fq12_one();
     for (int i = 0; i < n; i++) f = fq12_mul(f, miller_loop(load_g2(g2s + 32 * i), load_g1(g1s + 16 * i)));

@@ -172,6 +172,15 @@ def test_tower_and_pairing(libs):
         assert I12(out) == b.f12_mul(x, y)
         lib.emul_f12_mul(W12(x), W12(y), 1, out)
         assert I12(out) == b.f12_mul(x, x)
+    out2 = (ctypes.c_uint32 * 96)()
+    for _ in range(3):                                          # inverse; final exponentiation: easy/hard split == one 2790-bit power == oracle
+        x = [rnd.randrange(b.P) for _ in range(12)]
+        lib.emul_f12_inv(W12(x), out)
+        assert I12(out) == b.f12_inv(x)
+        lib.emul_f12_final_exp(W12(x), 0, out)
+        lib.emul_f12_final_exp(W12(x), 1, out2)
+        assert I12(out) == I12(out2)
+    assert I12(out) == b.final_exponentiate(x)
     g1w = lambda pt: [(pt[0] >> (32 * i)) & 0xFFFFFFFF for i in range(8)] + [(pt[1] >> (32 * i)) & 0xFFFFFFFF for i in range(8)]  # noqa: E731
 
     def g2w(pt):
