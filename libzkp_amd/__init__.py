@@ -13,8 +13,10 @@ from .api import (  # noqa: F401
     create_proof_batch, batch_add_range_proof, batch_add_equality_proof,
     batch_add_threshold_proof, batch_add_membership_proof, batch_add_improvement_proof, batch_add_consistency_proof,
     process_batch, get_batch_status, clear_batch, benchmark_proof_generation, benchmark_proof_generation_numeric,
+    open_batch_from_store, refresh_batch_from_store, export_batch_to_file, import_batch_from_file,
     ZkpBackendError,
 )
+from .batch_store import set_batch_store_dir, get_batch_store_dir, list_batch_ids_in_store  # noqa: F401
 from .composite import (  # noqa: F401
     create_composite_proof, verify_composite_proof, verify_composite_proof_integrity_only, create_proof_with_metadata,
     extract_proof_metadata, verify_proofs_parallel, validate_proof_chain, get_proof_info,
@@ -32,5 +34,7 @@ __all__ = [
     "process_batch", "get_batch_status", "clear_batch", "benchmark_proof_generation", "benchmark_proof_generation_numeric",
     "create_composite_proof", "verify_composite_proof", "verify_composite_proof_integrity_only", "create_proof_with_metadata",
     "extract_proof_metadata", "verify_proofs_parallel", "validate_proof_chain", "get_proof_info",
+    "open_batch_from_store", "refresh_batch_from_store", "export_batch_to_file", "import_batch_from_file",
+    "set_batch_store_dir", "get_batch_store_dir", "list_batch_ids_in_store",
     "NativeError", "ZkpBackendError",
 ]

@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-from . import _native
+from . import _native, batch_store
 
 U64_MAX = 2**64 - 1
 
@@ -530,13 +530,20 @@ _registry = {}
 _registry_lock = threading.Lock()
 
 
+def _allocate_batch_id():
+    while True:
+        bid = secrets.randbits(64)
+        if bid != 0 and bid not in _registry:
+            return bid
+
+
 def create_proof_batch():
+    """batch.rs:36-48; with a store directory configured every change is written through (batch_store.rs:157-162)."""
     with _registry_lock:
-        while True:
-            bid = secrets.randbits(64)
-            if bid != 0 and bid not in _registry:
-                _registry[bid] = []
-                return bid
+        bid = _allocate_batch_id()
+        _registry[bid] = []
+        batch_store.persist_batch_if_configured(bid, _registry[bid])
+        return bid
 
 
 def _with_batch(batch_id, op):
@@ -544,6 +551,43 @@ def _with_batch(batch_id, op):
         if batch_id not in _registry:
             raise ValueError("Invalid batch ID: %d" % batch_id)
         _registry[batch_id].append(op)
+        batch_store.persist_batch_if_configured(batch_id, _registry[batch_id])
+
+
+def open_batch_from_store(batch_id):
+    """batch.rs:192-210: cold start from the on-disk store."""
+    d = batch_store._store_dir_required()
+    with _registry_lock:
+        if batch_id in _registry:
+            raise ValueError("batch %d is already open in this process" % batch_id)
+        _registry[batch_id] = batch_store.read_batch_file(d, batch_id)
+
+
+def refresh_batch_from_store(batch_id):
+    """batch.rs:214-232: pick up what another process wrote."""
+    d = batch_store._store_dir_required()
+    with _registry_lock:
+        if batch_id not in _registry:
+            raise ValueError("batch %d is not loaded in this process" % batch_id)
+        _registry[batch_id] = batch_store.read_batch_file(d, batch_id)
+
+
+def export_batch_to_file(batch_id, dest):
+    """batch.rs:236-245"""
+    with _registry_lock:
+        if batch_id not in _registry:
+            raise ValueError("Invalid batch ID: %d" % batch_id)
+        batch_store.export_proof_batch_to_path(_registry[batch_id], dest)
+
+
+def import_batch_from_file(src):
+    """batch.rs:249-260: new batch id; persisted if a store is configured."""
+    ops = batch_store.import_proof_batch_from_path(src)
+    with _registry_lock:
+        bid = _allocate_batch_id()
+        _registry[bid] = ops
+        batch_store.persist_batch_if_configured(bid, ops)
+        return bid
 
 
 def batch_add_range_proof(batch_id, value, min, max):  # noqa: A002
@@ -594,6 +638,7 @@ def process_batch(batch_id, seeds=None):
         if batch_id not in _registry:
             raise ValueError("Invalid batch ID: %d" % batch_id)
         ops = _registry.pop(batch_id)
+    batch_store.delete_batch_file_if_configured(batch_id)            # batch.rs:120-121
     for op in ops:
         if op[0] == "membership" and len(op[2]) > MAX_SET_SIZE:      # set_membership.rs:14 (validate_set_size at prove time)
             raise ValueError("set size %d exceeds maximum allowed size %d" % (len(op[2]), MAX_SET_SIZE))
@@ -704,6 +749,7 @@ def get_batch_status(batch_id):
 def clear_batch(batch_id):
     with _registry_lock:
         _registry.pop(batch_id, None)
+    batch_store.delete_batch_file_if_configured(batch_id)            # batch.rs:183-184
 
 
 # ---------------------------------------------------------------- benchmark harness (advanced/mod.rs:83-172)
