@@ -44,14 +44,17 @@ void zkp_hip_shutdown(void);
 /* Thread-local description of the last failure of a call made on this thread. */
 const char* zkp_hip_last_error(void);
 
-/* Replaces a loop of proof::range_proof::prove_range(value, min, max)
+/* Replaces a loop of proof::range_proof::prove_range_with_bits(value, min, max, n_bits) -- prove_range is n_bits = 64 --
  * (/root/reference/src/proof/range_proof.rs:10-27 -> BulletproofsBackend::prove_range_with_bounds_bits,
  * /root/reference/src/backend/bulletproofs.rs:112-178) as issued by process_batch
  * (/root/reference/src/advanced/batch.rs:123-131,264-266).
  *   value,min,max : n host u64 each           seeds : 32*n host bytes or NULL
- *   out           : n records of `stride` bytes (stride >= 1478); record i holds the version-2 Proof envelope
- *   out_len[i]    : 1478 on success, 0 on failure      status[i] : per-item code (validation.rs:5-18)
- * n_bits must be 64 (what prove_range uses, range_proof.rs:10-12). */
+ *   n_bits        : 8, 16, 32 or 64, one width per call (others: ZKP_HIP_E_UNSUPPORTED, upstream's InvalidBitsize)
+ *   out           : n records of `stride` bytes; record i holds the version-2 Proof envelope of
+ *                   zkp_hip_range_proof_bytes(n_bits) bytes (1478 for 64 bits, 128 less per halving)
+ *   out_len[i]    : that size on success, 0 on failure      status[i] : per-item code (validation.rs:5-18; a width
+ *                   value - min or max - value does not fit in is ZKP_HIP_INVALID_INPUT, bulletproofs.rs:121-129) */
+uint64_t zkp_hip_range_proof_bytes(uint32_t n_bits);        /* 0 for an unsupported width */
 int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* min, const uint64_t* max, uint32_t n_bits,
                               const uint8_t* seeds, uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status);
 
@@ -62,9 +65,11 @@ int zkp_hip_prove_range_batch_device(uint64_t n, const uint64_t* d_value, const 
                                      const uint8_t* d_seeds, uint8_t* d_out, uint64_t stride, uint32_t* d_out_len, int32_t* d_status,
                                      void* stream, int* any_failed);
 
-/* Replaces a loop of proof::threshold_proof::prove_threshold(values, threshold)
- * (/root/reference/src/proof/threshold_proof.rs:12-32 -> bulletproofs.rs:309-366).  values = all ops' value lists
- * concatenated, counts[i] = length of op i's list.  One 762-byte envelope (scheme 3) per op; stride >= 762. */
+/* Replaces a loop of proof::threshold_proof::prove_threshold_with_bits(values, threshold, n_bits) -- prove_threshold is
+ * n_bits = 64 -- (/root/reference/src/proof/threshold_proof.rs:12-32 -> bulletproofs.rs:309-366).  values = all ops' value
+ * lists concatenated, counts[i] = length of op i's list.  One envelope (scheme 3) of
+ * zkp_hip_threshold_proof_bytes(n_bits) bytes per op (762 for 64 bits, 64 less per halving); stride >= that. */
+uint64_t zkp_hip_threshold_proof_bytes(uint32_t n_bits);    /* 0 for an unsupported width */
 int zkp_hip_prove_threshold_batch(uint64_t n, const uint64_t* values, const uint32_t* counts, const uint64_t* thresholds, uint32_t n_bits,
                                   const uint8_t* seeds, uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status);
 
@@ -100,9 +105,9 @@ int zkp_hip_prove_equality_batch(uint64_t n, const uint64_t* val1, const uint64_
 /* Replaces a loop of proof::range_proof::verify_range(proof, min, max) (range_proof.rs:28-47 ->
  * BulletproofsBackend::verify_range_with_bounds, bulletproofs.rs:181-295).  proofs = n envelopes at `stride` bytes,
  * lens[i] bytes used.  ok[i] = 1 accepted, 0 rejected (malformed framing, wrong bounds, invalid points/scalars, failed
- * verification equation), 2 = well-formed proof for n_bits != 64, which this backend does not verify (the reference's
- * prove_range always uses 64 bits, range_proof.rs:10-12).  The two verification equations of RangeProof::verify_single
- * are folded with a transcript-derived weight (as upstream does with a random one). */
+ * verification equation).  The bit width (8, 16, 32 or 64) is read from each envelope (bulletproofs.rs:211-216), so one
+ * batch may mix widths.  The two verification equations of RangeProof::verify_single are folded with a transcript-derived
+ * weight (as upstream does with a random one). */
 int zkp_hip_verify_range_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, const uint32_t* lens,
                                const uint64_t* mins, const uint64_t* maxs, uint8_t* ok);
 /* Same for proof::threshold_proof::verify_threshold(proof, threshold) (threshold_proof.rs:34-47 -> bulletproofs.rs:550-626):

@@ -5,7 +5,7 @@ for the path in scope: the six prove_* operations and the 
 HIP library behind the C ABI of include/libzkp_hip.h; there is no CPU fallback.
 """
 from .api import (  # noqa: F401
-    prove_range, prove_range_batch, verify_range, verify_range_batch, verify_threshold, verify_threshold_batch, verify_improvement, verify_improvement_batch, verify_consistency, verify_consistency_batch, verify_equality, verify_equality_with_commitment,
+    prove_range, prove_range_with_bits, prove_threshold_with_bits, prove_range_batch, verify_range, verify_range_batch, verify_threshold, verify_threshold_batch, verify_improvement, verify_improvement_batch, verify_consistency, verify_consistency_batch, verify_equality, verify_equality_with_commitment,
     verify_equality_with_commitment_batch, verify_membership, verify_membership_batch, prove_threshold, prove_threshold_batch, prove_consistency, prove_consistency_batch,
     prove_equality, prove_equality_batch, prove_equality_advanced, prove_membership, prove_membership_batch, prove_improvement,
     prove_improvement_batch, snark_commit_value,
@@ -24,7 +24,7 @@ from .composite import (  # noqa: F401
 from ._native import NativeError  # noqa: F401
 
 __all__ = [
-    "prove_range", "prove_range_batch", "verify_range", "verify_range_batch", "verify_threshold", "verify_threshold_batch", "verify_improvement", "verify_improvement_batch", "verify_consistency", "verify_consistency_batch", "verify_equality", "verify_equality_with_commitment",
+    "prove_range", "prove_range_with_bits", "prove_threshold_with_bits", "prove_range_batch", "verify_range", "verify_range_batch", "verify_threshold", "verify_threshold_batch", "verify_improvement", "verify_improvement_batch", "verify_consistency", "verify_consistency_batch", "verify_equality", "verify_equality_with_commitment",
     "verify_equality_with_commitment_batch", "verify_membership", "verify_membership_batch", "prove_threshold", "prove_threshold_batch", "prove_consistency", "prove_consistency_batch",
     "prove_equality", "prove_equality_batch", "prove_equality_advanced", "prove_membership", "prove_membership_batch", "prove_improvement",
     "prove_improvement_batch", "snark_commit_value",

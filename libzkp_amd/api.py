@@ -42,20 +42,39 @@ def _P(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def prove_range_batch(values, mins, maxs, seeds=None, device=None):
-    """Batched prove_range: returns a list of proof bytes (one 1478-byte envelope per op).
+BIT_WIDTHS = (8, 16, 32, 64)          # RangeProof::prove_single's valid bit sizes
+
+
+def max_u64_for_bit_width(n_bits):
+    """bulletproofs.rs:94-100"""
+    return 2**64 - 1 if n_bits >= 64 else (1 << n_bits) - 1
+
+
+def _check_bits(n_bits, what):
+    if n_bits not in BIT_WIDTHS:         # upstream: ProofError::InvalidBitsize -> "... proof generation failed"
+        raise ZkpBackendError("Backend error: %s proof generation failed (n_bits must be 8, 16, 32 or 64)" % what)
+    return int(n_bits)
+
+
+def prove_range_batch(values, mins, maxs, seeds=None, device=None, n_bits=64):
+    """Batched prove_range / prove_range_with_bits: returns a list of proof bytes (one envelope per op; 1478 bytes for
+    n_bits = 64, 128 fewer per halving of the width).
 
     Raises ValueError (reference message) if any op is invalid -- like process_batch, one failure fails the call.
     `seeds` (n x 32 bytes) pins the randomness tape; None draws fresh OS randomness like the reference.
     """
     n = len(values)
+    n_bits = _check_bits(n_bits, "min range")
     v = np.array([_check_u64("value", x) for x in values], dtype=np.uint64)
     mn = np.array([_check_u64("min", x) for x in mins], dtype=np.uint64)
     mx = np.array([_check_u64("max", x) for x in maxs], dtype=np.uint64)
     if not (len(mn) == n and len(mx) == n):
         raise ValueError("values, mins, maxs must have equal length")
+    cap = max_u64_for_bit_width(n_bits)
     for i in range(n):
         validate_range_params(int(v[i]), int(mn[i]), int(mx[i]))
+        if int(v[i]) - int(mn[i]) > cap or int(mx[i]) - int(v[i]) > cap:          # bulletproofs.rs:121-129
+            raise ZkpBackendError("Backend error: range width exceeds %d-bit capacity; use n_bits=64" % n_bits)
     if n == 0:
         return []
     L = _native.lib()
@@ -71,7 +90,7 @@ def prove_range_batch(values, mins, maxs, seeds=None, device=None):
     out = np.zeros((n, _native.RANGE_PROOF_BYTES), dtype=np.uint8)
     lens = np.zeros(n, dtype=np.uint32)
     st = np.zeros(n, dtype=np.int32)
-    rc = L.zkp_hip_prove_range_batch(n, _P(v), _P(mn), _P(mx), 64, sp, _P(out), _native.RANGE_PROOF_BYTES, _P(lens), _P(st))
+    rc = L.zkp_hip_prove_range_batch(n, _P(v), _P(mn), _P(mx), n_bits, sp, _P(out), _native.RANGE_PROOF_BYTES, _P(lens), _P(st))
     if rc < 0:
         raise ZkpBackendError("Backend error: %s" % _native.last_error())
     if rc > 0:
@@ -118,13 +137,17 @@ def validate_consistency_params(data):
         raise ValueError("data is not monotonic non-decreasing")
 
 
-def prove_threshold_batch(value_lists, thresholds, seeds=None):
-    """Batched prove_threshold (threshold_proof.rs:12-32): one 762-byte envelope per op."""
+def prove_threshold_batch(value_lists, thresholds, seeds=None, n_bits=64):
+    """Batched prove_threshold / prove_threshold_with_bits (threshold_proof.rs:12-32): one envelope per op (762 bytes for
+    n_bits = 64, 64 fewer per halving of the width)."""
     n = len(value_lists)
+    n_bits = _check_bits(n_bits, "threshold range")
     lists = [[_check_u64("value", x) for x in vl] for vl in value_lists]
     thr = [_check_u64("threshold", t) for t in thresholds]
     for vl, t in zip(lists, thr):
         validate_threshold_params(vl, t)
+        if sum(vl) - t > max_u64_for_bit_width(n_bits):                           # bulletproofs.rs:330-336
+            raise ZkpBackendError("Backend error: sum - threshold exceeds %d-bit capacity; use n_bits=64" % n_bits)
     if n == 0:
         return []
     flat = np.array([x for vl in lists for x in vl], dtype=np.uint64)
@@ -135,7 +158,7 @@ def prove_threshold_batch(value_lists, thresholds, seeds=None):
     out = np.zeros((n, stride), dtype=np.uint8)
     lens = np.zeros(n, dtype=np.uint32)
     st = np.zeros(n, dtype=np.int32)
-    rc = _native.lib().zkp_hip_prove_threshold_batch(n, _P(flat), _P(counts), _P(th), 64, sp, _P(out), stride, _P(lens), _P(st))
+    rc = _native.lib().zkp_hip_prove_threshold_batch(n, _P(flat), _P(counts), _P(th), n_bits, sp, _P(out), stride, _P(lens), _P(st))
     _raise_backend(rc, st, "threshold proof generation")
     return [out[i, : lens[i]].tobytes() for i in range(n)]
 
@@ -163,6 +186,11 @@ def prove_consistency_batch(data_lists, seeds=None):
 
 def prove_threshold(values, threshold):
     return prove_threshold_batch([list(values)], [threshold])[0]
+
+
+def prove_threshold_with_bits(values, threshold, n_bits):
+    """threshold_proof.rs:17-32: sum(values) - threshold must fit in n_bits (8, 16, 32 or 64)."""
+    return prove_threshold_batch([list(values)], [threshold], n_bits=n_bits)[0]
 
 
 def prove_consistency(data):
@@ -377,9 +405,7 @@ def verify_range_batch(proofs, mins, maxs):
     ok = np.zeros(n, dtype=np.uint8)
     rc = _native.lib().zkp_hip_verify_range_batch(n, _P(buf), stride, _P(lens), _P(mn), _P(mx), _P(ok))
     _native.check(rc, "zkp_hip_verify_range_batch")
-    if (ok == 2).any():
-        raise ZkpBackendError("Backend error: range proofs with n_bits != 64 are not verified by the HIP backend")
-    return [bool(x) for x in ok]
+    return [x == 1 for x in ok]
 
 
 def verify_threshold_batch(proofs, thresholds):
@@ -399,9 +425,7 @@ def verify_threshold_batch(proofs, thresholds):
         buf[i, : min(len(b), stride)] = np.frombuffer(b[:stride], dtype=np.uint8)
     ok = np.zeros(n, dtype=np.uint8)
     _native.check(_native.lib().zkp_hip_verify_threshold_batch(n, _P(buf), stride, _P(lens), _P(th), _P(ok)), "zkp_hip_verify_threshold_batch")
-    if (ok == 2).any():
-        raise ZkpBackendError("Backend error: threshold proofs with n_bits != 64 are not verified by the HIP backend")
-    return [bool(x) for x in ok]
+    return [x == 1 for x in ok]
 
 
 def _verify_snark_envelopes(kind, blobs):
@@ -523,6 +547,13 @@ def prove_range(value, min, max):  # noqa: A002  (reference argument names)
     value, mn, mx = _check_u64("value", value), _check_u64("min", min), _check_u64("max", max)
     validate_range_params(value, mn, mx)
     return prove_range_batch([value], [mn], [mx])[0]
+
+
+def prove_range_with_bits(value, min, max, n_bits):  # noqa: A002
+    """range_proof.rs:14-27: value - min and max - value must both fit in n_bits (8, 16, 32 or 64)."""
+    value, mn, mx = _check_u64("value", value), _check_u64("min", min), _check_u64("max", max)
+    validate_range_params(value, mn, mx)
+    return prove_range_batch([value], [mn], [mx], n_bits=n_bits)[0]
 
 
 # ---------------------------------------------------------------- batch registry (batch.rs:18-175)

@@ -139,23 +139,26 @@ inline MsmLayout make_layout_even(const std::vector<SlotList>& targets, uint32_t
     }
     return L;
 }
-inline std::vector<SlotList> targets_phase1() {
+// n = bits per proof (8, 16, 32, 64): party 0's first n generators of each chain (BulletproofGens::new(n, 2)); slot order
+// = the digit rows bp_steps.h writes for that n
+inline std::vector<SlotList> targets_phase1(uint32_t n = BP_N) {
     SlotList v = {{BASE_B, NWIN_U64}, {BASE_BB, NWIN}}, a = {{BASE_BB, NWIN}}, s = {{BASE_BB, NWIN}};
-    for (uint32_t i = 0; i < BP_N; i++) a.push_back({(uint16_t)(BASE_G + i), 1});
-    for (uint32_t i = 0; i < BP_N; i++) a.push_back({(uint16_t)(BASE_H + i), 1});
-    for (uint32_t i = 0; i < BP_N; i++) s.push_back({(uint16_t)(BASE_G + i), NWIN});
-    for (uint32_t i = 0; i < BP_N; i++) s.push_back({(uint16_t)(BASE_H + i), NWIN});
+    for (uint32_t i = 0; i < n; i++) a.push_back({(uint16_t)(BASE_G + i), 1});
+    for (uint32_t i = 0; i < n; i++) a.push_back({(uint16_t)(BASE_H + i), 1});
+    for (uint32_t i = 0; i < n; i++) s.push_back({(uint16_t)(BASE_G + i), NWIN});
+    for (uint32_t i = 0; i < n; i++) s.push_back({(uint16_t)(BASE_H + i), NWIN});
     return {v, a, s};
 }
 inline std::vector<SlotList> targets_phase2() { SlotList t = {{BASE_B, NWIN}, {BASE_BB, NWIN}}; return {t, t}; }
-inline std::vector<SlotList> targets_round(uint32_t r) {
-    const uint32_t p = 5 - r, k = 1u << p;
+inline std::vector<SlotList> targets_round(uint32_t r, uint32_t n = BP_N) {
+    uint32_t lg = 0; while ((1u << lg) < n) lg++;
+    const uint32_t p = lg - 1 - r, k = 1u << p, half = n / 2;
     auto idx = [&](uint32_t rank, uint32_t bit) { return ((rank >> p) << (p + 1)) | (bit << p) | (rank & (k - 1)); };
     SlotList l = {{BASE_B, NWIN}}, rr = {{BASE_B, NWIN}};
-    for (uint32_t q = 0; q < 32; q++) l.push_back({(uint16_t)(BASE_G + idx(q, 1)), NWIN});
-    for (uint32_t q = 0; q < 32; q++) l.push_back({(uint16_t)(BASE_H + idx(q, 0)), NWIN});
-    for (uint32_t q = 0; q < 32; q++) rr.push_back({(uint16_t)(BASE_G + idx(q, 0)), NWIN});
-    for (uint32_t q = 0; q < 32; q++) rr.push_back({(uint16_t)(BASE_H + idx(q, 1)), NWIN});
+    for (uint32_t q = 0; q < half; q++) l.push_back({(uint16_t)(BASE_G + idx(q, 1)), NWIN});
+    for (uint32_t q = 0; q < half; q++) l.push_back({(uint16_t)(BASE_H + idx(q, 0)), NWIN});
+    for (uint32_t q = 0; q < half; q++) rr.push_back({(uint16_t)(BASE_G + idx(q, 0)), NWIN});
+    for (uint32_t q = 0; q < half; q++) rr.push_back({(uint16_t)(BASE_H + idx(q, 1)), NWIN});
     return {l, rr};
 }
 inline std::vector<SlotList> targets_ctask() { return {SlotList{{BASE_B, NWIN_U64}, {BASE_BB, NWIN}}}; }
@@ -166,9 +169,9 @@ inline std::vector<SlotList> targets_verify() {
     for (uint32_t i = 0; i < BP_N; i++) t.push_back({(uint16_t)(BASE_H + i), NWIN});
     return {t};
 }
-inline MsmLayout layout_phase1(uint32_t budget) { return make_layout(targets_phase1(), budget); }
+inline MsmLayout layout_phase1(uint32_t budget, uint32_t n = BP_N) { return make_layout(targets_phase1(n), budget); }
 inline MsmLayout layout_phase2(uint32_t budget) { return make_layout(targets_phase2(), budget); }
-inline MsmLayout layout_round(uint32_t r, uint32_t budget) { return make_layout(targets_round(r), budget); }
+inline MsmLayout layout_round(uint32_t r, uint32_t budget, uint32_t n = BP_N) { return make_layout(targets_round(r, n), budget); }
 inline MsmLayout layout_ctask(uint32_t budget) { return make_layout(targets_ctask(), budget); }
 
 }  // namespace zkp

@@ -1,4 +1,4 @@
-// Per-thread steps of the batched Bulletproofs single-value range prover (n = 64, m = 1).
+// Per-thread steps of the batched Bulletproofs single-value range prover (n = 8, 16, 32 or 64 bits per batch; m = 1).
 //
 // What is computed follows bulletproofs::RangeProof::prove_single as the reference calls it
 // (/root/reference/src/backend/bulletproofs.rs:138-158,344-352,396-404,643-653; protocol restated in
@@ -18,22 +18,28 @@
 
 namespace zkp {
 
-constexpr uint32_t BP_N = 64;
+constexpr uint32_t BP_N = 64;          // widest proof; workspace strides and generator tables are sized for it
 constexpr uint32_t BASE_B = 0, BASE_BB = 1, BASE_G = 2, BASE_H = 66, NBASE = 130;
 // fixed-base tables of the 130 generators: signed radix-1024 digits -> 26 windows of 512 affine-niels entries (208 MB);
 // a 64-bit value needs 7 windows.  (The Groth16 key tables use radix 256: G16_* in g16_steps.h.)
 constexpr uint32_t WBITS = 10, NWIN = 26, NENT = 512, DIGW = 13, NWIN_U64 = 7, NIELS_W = 30, SUBTAB_W = NENT * NIELS_W;
 constexpr uint32_t TAPE_SLOTS = 132;
 // phase-1 MSM slots: V = v*B + gamma*B~ ; A = a_bl*B~ + sum bit_i*G_i + (bit_i-1)*H_i ; S = s_bl*B~ + sum sL_i*G_i + sR_i*H_i
-constexpr uint32_t P1_V = 0, P1_A = 2, P1_S = 131, P1_NSLOTS = 260;
+// Slot numbers are compact for the batch's bit width n (so a launch's slot index is also its digit row): A's slots start at
+// P1_A, S's at p1_s(n) = 3 + 2n; the capacities below are those of n = 64.
+constexpr uint32_t P1_V = 0, P1_A = 2, P1_NSLOTS = 260;
 constexpr uint32_t P2_NSLOTS = 4;      // T1: t1*B + t1_bl*B~ ; T2: t2*B + t2_bl*B~
-constexpr uint32_t PR_NSLOTS = 130;    // L: c_L*w*B + 32 G + 32 H ; R likewise
+constexpr uint32_t PR_NSLOTS = 130;    // L: c_L*w*B + n/2 G + n/2 H ; R likewise  (slot n+1 starts R)
+ZKP_HD constexpr uint32_t p1_s(uint32_t n) { return 3 + 2 * n; }
+ZKP_HD constexpr uint32_t tape_slots(uint32_t n) { return 2 * n + 4; }
+ZKP_HD constexpr uint32_t rp_bytes(uint32_t lg) { return 32 * (9 + 2 * lg); }     // RangeProof::to_bytes: 9 + 2 lg n elements
 constexpr uint32_t GE_W = 40;
 enum { SC_Y = 0, SC_Z, SC_X, SC_W, SC_U, SC_UINV, SC_T0, SC_T1, SC_T2, SC_NUM };
 enum { KIND_RANGE_MIN = 0, KIND_RANGE_MAX, KIND_THRESHOLD, KIND_CONSISTENCY, KIND_BULLETPROOF, KIND_NUM };
 
 struct BpView {
     uint32_t M;                    // number of proof jobs
+    uint32_t n, lg;                // bits per proof (8, 16, 32, 64) and log2 of it: one width per batch
     // job description (read-only)
     const uint64_t* v;             // [M] value in [0, 2^64)
     const uint32_t* seed_ix;       // [M] which 32-byte seed
@@ -97,19 +103,19 @@ ZKP_HD inline sc tape_blinding(const uint32_t seed[8], uint32_t i) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// step 0: randomness tape + phase-1 digits.  thread = (slot in [0, 133), job)
+// step 0: randomness tape + phase-1 digits.  thread = (slot in [0, 2n + 5), job)
 ZKP_HD inline void step_tape(const BpView& V, uint32_t slot, uint32_t job) {
-    const uint32_t M = V.M;
+    const uint32_t M = V.M, n = V.n, P1_S = p1_s(V.n);
     uint32_t seed[8]; ld_seed(seed, V, job);
-    if (slot < TAPE_SLOTS) {
+    if (slot < tape_slots(n)) {
         uint32_t w[16]; tape_draw64(w, seed, V.proof_ix[job], slot);
         const sc x = sc_from_wide(w);
         st_sc(V.tape, slot, job, M, x);
         if (slot == 0) st_digits(V.d1, P1_A + 0, job, M, x);                            // a_blinding * B~
         else if (slot == 1) st_digits(V.d1, P1_S + 0, job, M, x);                       // s_blinding * B~
-        else if (slot < 2 + BP_N) st_digits(V.d1, P1_S + 1 + (slot - 2), job, M, x);    // s_L[i] * G_i
-        else if (slot < 2 + 2 * BP_N) st_digits(V.d1, P1_S + 1 + BP_N + (slot - 2 - BP_N), job, M, x);  // s_R[i] * H_i
-        else if (slot == 2 + 2 * BP_N) st_digits(V.d2, 1, job, M, x);                   // t1_blinding * B~
+        else if (slot < 2 + n) st_digits(V.d1, P1_S + 1 + (slot - 2), job, M, x);    // s_L[i] * G_i
+        else if (slot < 2 + 2 * n) st_digits(V.d1, P1_S + 1 + n + (slot - 2 - n), job, M, x);  // s_R[i] * H_i
+        else if (slot == 2 + 2 * n) st_digits(V.d2, 1, job, M, x);                   // t1_blinding * B~
         else st_digits(V.d2, 3, job, M, x);                                             // t2_blinding * B~
     } else {
         sc g = sc_zero();
@@ -120,10 +126,10 @@ ZKP_HD inline void step_tape(const BpView& V, uint32_t slot, uint32_t job) {
         const uint64_t v = V.v[job];
         st_digits_raw(V.d1, P1_V + 0, job, M, sc_words((uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0));
         // A: bit_i * G_i + (bit_i - 1) * H_i  -> single-window digits (+1 / 0 and 0 / -1)
-        for (uint32_t i = 0; i < BP_N; i++) {
+        for (uint32_t i = 0; i < n; i++) {
             const uint32_t bit = (uint32_t)(v >> i) & 1u;
             V.d1[(size_t)(P1_A + 1 + i) * DIGW * M + job] = bit;
-            V.d1[(size_t)(P1_A + 1 + BP_N + i) * DIGW * M + job] = bit ? 0u : 0xFFFFu;
+            V.d1[(size_t)(P1_A + 1 + n + i) * DIGW * M + job] = bit ? 0u : 0xFFFFu;
         }
     }
 }
@@ -227,7 +233,7 @@ ZKP_HD inline void step_transcript1(const BpView& V, uint32_t job, Strobe& s) {
         default: merlin_init(s, "libzkp_bulletproof", 18); break;
     }
     merlin_append_bytes(s, "dom-sep", 7, "rangeproof v1", 13);
-    merlin_append_u64(s, "n", 1, BP_N);
+    merlin_append_u64(s, "n", 1, V.n);
     merlin_append_u64(s, "m", 1, 1);
     const sc Ve = ld_sc(V.enc, 0, job, M), Ae = ld_sc(V.enc, 1, job, M), Se = ld_sc(V.enc, 2, job, M);
     merlin_append_words(s, "V", 1, Ve.v, 8);
@@ -266,7 +272,7 @@ ZKP_HD inline void step_poly(const BpView& V, uint32_t i, uint32_t job) {
     const sc two_i = sc_from_u64(1ull << i);
     const sc r0 = sc_add(sc_mul(yi, arz), sc_mul(zz, two_i));
     const sc l1 = ld_sc(V.tape, 2 + i, job, M);
-    const sc r1 = sc_mul(yi, ld_sc(V.tape, 2 + BP_N + i, job, M));
+    const sc r1 = sc_mul(yi, ld_sc(V.tape, 2 + V.n + i, job, M));
     st_sc(V.r0, i, job, M, r0); st_sc(V.r1, i, job, M, r1);
     st_sc(V.pp, i, job, M, sc_mul(l0, r0));
     st_sc(V.pp, 64 + i, job, M, sc_mul(sc_add(l0, l1), sc_add(r0, r1)));
@@ -280,7 +286,7 @@ ZKP_HD inline ScTriple triple_add(const ScTriple& x, const ScTriple& y) { return
 ZKP_HD inline ScTriple step_poly_sum_part(const BpView& V, uint32_t part, uint32_t job) {
     const uint32_t M = V.M;
     ScTriple t{sc_zero(), sc_zero(), sc_zero()};
-    for (uint32_t i = part; i < BP_N; i += 8) {
+    for (uint32_t i = part; i < V.n; i += 8) {
         t.a = sc_add(t.a, ld_sc(V.pp, i, job, M));
         t.b = sc_add(t.b, ld_sc(V.pp, 64 + i, job, M));
         t.c = sc_add(t.c, ld_sc(V.pp, 128 + i, job, M));
@@ -311,7 +317,7 @@ ZKP_HD inline void step_transcript2(const BpView& V, uint32_t job, Strobe& s) {
     const sc z = ld_sc(V.scal, SC_Z, job, M), zz = sc_mul(z, z);
     const sc t0 = ld_sc(V.scal, SC_T0, job, M), t1 = ld_sc(V.scal, SC_T1, job, M), t2 = ld_sc(V.scal, SC_T2, job, M);
     const sc t_x = sc_add(sc_add(t0, sc_mul(t1, x)), sc_mul(t2, xx));
-    const sc t1_bl = ld_sc(V.tape, 2 + 2 * BP_N, job, M), t2_bl = ld_sc(V.tape, 3 + 2 * BP_N, job, M);
+    const sc t1_bl = ld_sc(V.tape, 2 + 2 * V.n, job, M), t2_bl = ld_sc(V.tape, 3 + 2 * V.n, job, M);
     const sc t_x_bl = sc_add(sc_add(sc_mul(zz, ld_sc(V.gamma, 0, job, M)), sc_mul(t1_bl, x)), sc_mul(t2_bl, xx));
     const sc e_bl = sc_add(ld_sc(V.tape, 0, job, M), sc_mul(ld_sc(V.tape, 1, job, M), x));
     const sc r_tx = sc_to_raw(t_x), r_txb = sc_to_raw(t_x_bl), r_eb = sc_to_raw(e_bl);
@@ -320,7 +326,7 @@ ZKP_HD inline void step_transcript2(const BpView& V, uint32_t job, Strobe& s) {
     merlin_append_scalar(s, "e_blinding", 10, r_eb);
     const sc w = merlin_challenge_scalar(s, "w", 1);
     merlin_append_bytes(s, "dom-sep", 7, "ipp v1", 6);
-    merlin_append_u64(s, "n", 1, BP_N);
+    merlin_append_u64(s, "n", 1, V.n);
     strobe_save(V, job, s);
     st_sc(V.scal, SC_X, job, M, x); st_sc(V.scal, SC_W, job, M, w);
     uint8_t* pr = V.out + V.proof_off[job];
@@ -338,10 +344,10 @@ ZKP_HD inline void step_lr_init(const BpView& V, uint32_t i, uint32_t job) {
     st_sc(V.ab, i, job, M, a); st_sc(V.ab, 64 + i, job, M, b);
 }
 
-// inner-product round r (k = 32 >> r): fold a, b and the per-generator coefficients, emit MSM digits.
-// thread = (i, job), i in [0, 64)
+// inner-product round r (k = n/2 >> r): fold a, b and the per-generator coefficients, emit MSM digits.
+// thread = (i, job), i in [0, n)
 ZKP_HD inline void step_round_prep(const BpView& V, uint32_t r, uint32_t i, uint32_t job) {
-    const uint32_t M = V.M, p = 5 - r, k = 1u << p;
+    const uint32_t M = V.M, p = V.lg - 1 - r, k = 1u << p, half = V.n >> 1;
     const uint32_t* abp = V.ab + (size_t)(r & 1) * (2 * 64 * 8) * M;
     uint32_t* abn = V.ab + (size_t)((r + 1) & 1) * (2 * 64 * 8) * M;
     sc u = sc_one(), uinv = sc_one();
@@ -367,8 +373,8 @@ ZKP_HD inline void step_round_prep(const BpView& V, uint32_t r, uint32_t i, uint
     const sc ax = cur_a(x), bx = cur_b(x);
     if (i < 2 * k) { st_sc(abn, x, job, M, ax); st_sc(abn, 64 + x, job, M, bx); }
     const uint32_t bit = (i >> p) & 1u, rank = ((i >> (p + 1)) << p) | (i & (k - 1));
-    st_digits(V.dr, bit ? 1 + rank : 66 + rank, job, M, sc_mul(ax, g));
-    st_digits(V.dr, bit ? 98 + rank : 33 + rank, job, M, sc_mul(bx, h));
+    st_digits(V.dr, bit ? 1 + rank : V.n + 2 + rank, job, M, sc_mul(ax, g));                    // L's G terms | R's G terms
+    st_digits(V.dr, bit ? V.n + 2 + half + rank : 1 + half + rank, job, M, sc_mul(bx, h));      // R's H terms | L's H terms
     if (i < k) {   // here x = i + k
         const sc ai = cur_a(i), bi = cur_b(i);
         st_sc(V.pp, i, job, M, sc_mul(ai, bx));        // a_lo[i] * b_hi[i]
@@ -377,12 +383,12 @@ ZKP_HD inline void step_round_prep(const BpView& V, uint32_t r, uint32_t i, uint
 }
 // thread = job
 ZKP_HD inline void step_round_sum(const BpView& V, uint32_t r, uint32_t job) {
-    const uint32_t M = V.M, k = 32u >> r;
+    const uint32_t M = V.M, k = (V.n >> 1) >> r;
     sc cL = sc_zero(), cR = sc_zero();
     for (uint32_t j = 0; j < k; j++) { cL = sc_add(cL, ld_sc(V.pp, j, job, M)); cR = sc_add(cR, ld_sc(V.pp, 32 + j, job, M)); }
     const sc w = ld_sc(V.scal, SC_W, job, M);
     st_digits(V.dr, 0, job, M, sc_mul(cL, w));
-    st_digits(V.dr, 65, job, M, sc_mul(cR, w));
+    st_digits(V.dr, V.n + 1, job, M, sc_mul(cR, w));
 }
 // thread = job
 ZKP_HD inline void step_transcript_round(const BpView& V, uint32_t r, uint32_t job, Strobe& s) {
@@ -395,15 +401,15 @@ ZKP_HD inline void step_transcript_round(const BpView& V, uint32_t r, uint32_t j
     const sc uinv = sc_invert(u);
     uint8_t* pr = V.out + V.proof_off[job];
     put_bytes(pr + 224 + 64 * r, Le.v, 8); put_bytes(pr + 256 + 64 * r, Re.v, 8);
-    if (r < 5) {
+    if (r + 1 < V.lg) {
         strobe_save(V, job, s);
         st_sc(V.scal, SC_U, job, M, u); st_sc(V.scal, SC_UINV, job, M, uinv);
     } else {
-        const uint32_t* abp = V.ab;   // buffer (5+1)&1 = 0 holds the length-2 vectors
+        const uint32_t* abp = V.ab + (size_t)(V.lg & 1u) * (2 * 64 * 8) * M;   // the buffer the last round wrote holds the length-2 vectors
         const sc a = sc_add(sc_mul(ld_sc(abp, 0, job, M), u), sc_mul(ld_sc(abp, 1, job, M), uinv));
         const sc b = sc_add(sc_mul(ld_sc(abp, 64, job, M), uinv), sc_mul(ld_sc(abp, 65, job, M), u));
         const sc ra = sc_to_raw(a), rb = sc_to_raw(b);
-        put_bytes(pr + 608, ra.v, 8); put_bytes(pr + 640, rb.v, 8);
+        put_bytes(pr + 224 + 64 * V.lg, ra.v, 8); put_bytes(pr + 256 + 64 * V.lg, rb.v, 8);
     }
 }
 
@@ -436,12 +442,17 @@ struct JobBuf {
 constexpr uint32_t RANGE_PROOF_BYTES = 1478, RP_BYTES = 672;
 enum { ZKP_ST_OK = 0, ZKP_ST_INVALID_INPUT = 1 };
 ZKP_HD inline void put_le(uint8_t* p, uint64_t x, int n) { for (int i = 0; i < n; i++) p[i] = (uint8_t)(x >> (8 * i)); }
-ZKP_HD inline void step_build_range(const JobBuf& J, uint32_t op, const uint64_t* value, const uint64_t* mn, const uint64_t* mx,
+ZKP_HD constexpr uint32_t range_body_bytes(uint32_t lg) { return 20 + 2 * (4 + rp_bytes(lg)) + 64; }   // bulletproofs.rs:160-177
+ZKP_HD constexpr uint32_t range_envelope_bytes(uint32_t lg) { return 10 + range_body_bytes(lg) + 32; }
+ZKP_HD inline void step_build_range(const JobBuf& J, uint32_t op, const uint64_t* value, const uint64_t* mn, const uint64_t* mx, uint32_t lg,
                                     uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
     const uint64_t val = value[op], lo = mn[op], hi = mx[op];
-    const bool ok = lo <= hi && val >= lo && val <= hi;            // validation.rs:5-18
+    const uint64_t max_diff = lg >= 6 ? ~0ull : (1ull << (1u << lg)) - 1;      // bulletproofs.rs:94-100,121-129
+    const bool ok = lo <= hi && val >= lo && val <= hi                  // validation.rs:5-18
+                    && val - lo <= max_diff && hi - val <= max_diff;
+    const uint32_t RP_BYTES = rp_bytes(lg), body = range_body_bytes(lg);
     status[op] = ok ? ZKP_ST_OK : ZKP_ST_INVALID_INPUT;
-    out_len[op] = ok ? RANGE_PROOF_BYTES : 0;
+    out_len[op] = ok ? range_envelope_bytes(lg) : 0;
     const uint64_t base = (uint64_t)op * stride;
     for (uint32_t j = 0; j < 2; j++) {
         const uint32_t job = 2 * op + j;
@@ -453,10 +464,10 @@ ZKP_HD inline void step_build_range(const JobBuf& J, uint32_t op, const uint64_t
         J.commit_off[job] = base + 10 + 20 + 2 * (4 + RP_BYTES) + 32 * j;
     }
     J.ct_v[op] = ok ? val : 0; J.ct_seed_ix[op] = op; J.ct_bl_ix[op] = 0;
-    J.ct_off[op] = base + 10 + 1436;
+    J.ct_off[op] = base + 10 + body;
     uint8_t* o = out + base;
-    o[0] = 2; o[1] = 1; put_le(o + 2, 1436, 4); put_le(o + 6, 32, 4);
-    put_le(o + 10, lo, 8); put_le(o + 18, hi, 8); put_le(o + 26, 64, 4);
+    o[0] = 2; o[1] = 1; put_le(o + 2, body, 4); put_le(o + 6, 32, 4);
+    put_le(o + 10, lo, 8); put_le(o + 18, hi, 8); put_le(o + 26, 1u << lg, 4);
     put_le(o + 30, RP_BYTES, 4); put_le(o + 34 + RP_BYTES, RP_BYTES, 4);
 }
 

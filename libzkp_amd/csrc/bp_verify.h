@@ -20,7 +20,7 @@ namespace zkp {
 
 enum { VP_V = 0, VP_A, VP_S, VP_T1, VP_T2, VP_L = 5, VP_R = 11, VP_NUM = 17 };
 enum { VS_Z = 0, VS_ZZ, VS_YINV, VS_A, VS_B, VS_U = 5, VS_UINV = 11, VS_NUM = 17 };
-constexpr int32_t VFY_UNSUPPORTED = 2;      // n_bits other than 64 (the reference's prove_range always uses 64, range_proof.rs:10-12)
+constexpr int32_t VFY_UNSUPPORTED = 2;      // reserved verdict (every bit width the reference accepts -- 8, 16, 32, 64 -- is verified)
 
 struct VfyView {
     uint32_t M;                   // jobs
@@ -28,6 +28,7 @@ struct VfyView {
     uint64_t* proof_off;          // [M] byte offset of the job's 672-byte RangeProof
     uint64_t* venc_off;           // [M] byte offset of the job's 32-byte value commitment encoding
     uint8_t* kind;                // [M] transcript label
+    uint8_t* lgn;                 // [M] log2 of the job's bit width (read from the envelope: bulletproofs.rs:211-216,567-572)
     int32_t* bad;                 // [M] nonzero: reject (1) / unsupported (2)
     uint32_t* pts;                // [17][40][M] decoded proof points
     uint32_t* scal;               // [VS_NUM][8][M] Montgomery-form scalars shared between steps
@@ -107,7 +108,7 @@ ZKP_HD inline ge ge_scalarmult_raw(const ge& P, const sc& k) {
 // ---- step 0: envelope framing (bulletproofs.rs:181-295 through proof_helpers.rs:12-36).  thread = envelope
 ZKP_HD inline void step_vparse(const VfyView& V, uint32_t i, const uint8_t* env, uint64_t env_off, uint32_t len, uint64_t mn, uint64_t mx) {
     const uint32_t j0 = 2 * i, j1 = 2 * i + 1;
-    V.kind[j0] = KIND_RANGE_MIN; V.kind[j1] = KIND_RANGE_MAX;
+    V.kind[j0] = KIND_RANGE_MIN; V.kind[j1] = KIND_RANGE_MAX; V.lgn[j0] = V.lgn[j1] = 6;
     V.proof_off[j0] = V.proof_off[j1] = 0; V.venc_off[j0] = V.venc_off[j1] = 0;
     V.bad[j0] = V.bad[j1] = 1;
     if (mn > mx || len < 10 || len > 1024u * 1024u || env[0] != 2 || env[1] != 1) return;
@@ -145,8 +146,9 @@ ZKP_HD inline void step_vparse(const VfyView& V, uint32_t i, const uint8_t* env,
     ge_ristretto_encode(e1, ge_add(vc, ge_neg(mb)));
     ge_ristretto_encode(e2, ge_add(xb, ge_neg(vc)));
     for (int k = 0; k < 8; k++) if (e1[k] != wm[k] || e2[k] != wx[k]) return;
-    if (n_bits != 64) { V.bad[j0] = V.bad[j1] = VFY_UNSUPPORTED; return; }
-    if (rl[0] != RP_BYTES || rl[1] != RP_BYTES) return;
+    uint32_t lg = 3; while ((1u << lg) != n_bits) lg++;
+    if (rl[0] != rp_bytes(lg) || rl[1] != rp_bytes(lg)) return;
+    V.lgn[j0] = V.lgn[j1] = (uint8_t)lg;
     V.proof_off[j0] = env_off + 10 + rp[0]; V.proof_off[j1] = env_off + 10 + rp[1];
     V.venc_off[j0] = env_off + 10 + pos; V.venc_off[j1] = env_off + 10 + pos + 32;
     V.bad[j0] = V.bad[j1] = 0;
@@ -155,7 +157,7 @@ ZKP_HD inline void step_vparse(const VfyView& V, uint32_t i, const uint8_t* env,
 // ---- step 0 for threshold proofs (threshold_proof.rs:34-47 + bulletproofs.rs:550-626): one job per envelope, the
 // sub-proof's commitment must be C - threshold*B.  thread = envelope
 ZKP_HD inline void step_vparse_threshold(const VfyView& V, uint32_t i, const uint8_t* env, uint64_t env_off, uint32_t len, uint64_t threshold) {
-    V.kind[i] = KIND_THRESHOLD; V.proof_off[i] = 0; V.venc_off[i] = 0; V.bad[i] = 1;
+    V.kind[i] = KIND_THRESHOLD; V.lgn[i] = 6; V.proof_off[i] = 0; V.venc_off[i] = 0; V.bad[i] = 1;
     if (len < 10 || len > 1024u * 1024u || env[0] != 2 || env[1] != 3) return;
     const uint32_t bl = ld_u32(env + 2), cl = ld_u32(env + 6);
     if (bl > 900u * 1024u || cl != 32 || (uint64_t)10 + bl + cl != len) return;
@@ -180,8 +182,9 @@ ZKP_HD inline void step_vparse_threshold(const VfyView& V, uint32_t i, const uin
     uint32_t e[8];
     ge_ristretto_encode(e, ge_add(sp, ge_neg(tb)));
     for (int k = 0; k < 8; k++) if (e[k] != wd[k]) return;
-    if (n_bits != 64) { V.bad[i] = VFY_UNSUPPORTED; return; }
-    if (rl != RP_BYTES) return;
+    uint32_t lg = 3; while ((1u << lg) != n_bits) lg++;
+    if (rl != rp_bytes(lg)) return;
+    V.lgn[i] = (uint8_t)lg;
     V.proof_off[i] = env_off + 10 + 16; V.venc_off[i] = env_off + 10 + 16 + rl; V.bad[i] = 0;
 }
 
@@ -189,7 +192,7 @@ ZKP_HD inline void step_vparse_threshold(const VfyView& V, uint32_t i, const uin
 // proofs of the successive differences, SHA-256 of the commitments as the envelope commitment.  thread = envelope
 ZKP_HD inline void step_vparse_consistency(const VfyView& V, uint32_t e, const uint8_t* env, uint64_t env_off, uint32_t len) {
     const uint32_t jb = V.job_base[e], je = V.job_base[e + 1];
-    for (uint32_t j = jb; j < je; j++) { V.kind[j] = KIND_CONSISTENCY; V.proof_off[j] = 0; V.venc_off[j] = 0; V.bad[j] = 1; }
+    for (uint32_t j = jb; j < je; j++) { V.kind[j] = KIND_CONSISTENCY; V.lgn[j] = 6; V.proof_off[j] = 0; V.venc_off[j] = 0; V.bad[j] = 1; }
     V.env_bad[e] = 1;
     if (len < 10 || len > 1024u * 1024u || env[0] != 2 || env[1] != 6) return;
     const uint32_t bl = ld_u32(env + 2), cl = ld_u32(env + 6);
@@ -238,9 +241,10 @@ ZKP_HD inline void step_vfinal_ranges(const VfyView& V, const uint32_t* enc, uin
     ok[e] = (uint8_t)verdict;
 }
 
-// ---- step 1: decode the 17 points of a job.  thread = (p, job)
+// ---- step 1: decode the 5 + 2 lg n points of a job.  thread = (p, job)
+ZKP_HD inline bool vpoint_present(uint32_t p, uint32_t lg) { return p < VP_L || (p < VP_R ? p - VP_L : p - VP_R) < lg; }
 ZKP_HD inline void step_vdecode(const VfyView& V, uint32_t p, uint32_t job) {
-    if (V.bad[job]) return;
+    if (V.bad[job] || !vpoint_present(p, V.lgn[job])) return;
     const uint8_t* pr = V.in + V.proof_off[job];
     const uint8_t* src = p == VP_V ? V.in + V.venc_off[job] : p < VP_L ? pr + 32 * (p - VP_A) : p < VP_R ? pr + 224 + 64 * (p - VP_L) : pr + 224 + 64 * (p - VP_R) + 32;
     uint32_t w[8]; ld_bytes_words(w, src, 8);
@@ -253,11 +257,11 @@ ZKP_HD inline void step_vdecode(const VfyView& V, uint32_t p, uint32_t job) {
 // ---- step 2: transcript replay, job-level scalars.  thread = job
 ZKP_HD inline void step_vtranscript(const VfyView& V, uint32_t job, Strobe& s) {
     if (V.bad[job]) return;
-    const uint32_t M = V.M;
+    const uint32_t M = V.M, lg = V.lgn[job], n = 1u << lg;
     const uint8_t* pr = V.in + V.proof_off[job];
     sc r_tx, r_txb, r_eb, r_a, r_b;
     ld_bytes_words(r_tx.v, pr + 128, 8); ld_bytes_words(r_txb.v, pr + 160, 8); ld_bytes_words(r_eb.v, pr + 192, 8);
-    ld_bytes_words(r_a.v, pr + 608, 8); ld_bytes_words(r_b.v, pr + 640, 8);
+    ld_bytes_words(r_a.v, pr + 224 + 64 * lg, 8); ld_bytes_words(r_b.v, pr + 256 + 64 * lg, 8);
     if (!sc_raw_is_canonical(r_tx) || !sc_raw_is_canonical(r_txb) || !sc_raw_is_canonical(r_eb) || !sc_raw_is_canonical(r_a) || !sc_raw_is_canonical(r_b)) { V.bad[job] = 1; return; }
     switch (V.kind[job]) {
         case KIND_RANGE_MIN: merlin_init(s, "libzkp_range_min", 16); break;
@@ -266,7 +270,7 @@ ZKP_HD inline void step_vtranscript(const VfyView& V, uint32_t job, Strobe& s) {
         default: merlin_init(s, "libzkp_threshold", 16); break;
     }
     merlin_append_bytes(s, "dom-sep", 7, "rangeproof v1", 13);
-    merlin_append_u64(s, "n", 1, BP_N);
+    merlin_append_u64(s, "n", 1, n);
     merlin_append_u64(s, "m", 1, 1);
     uint32_t w[8];
     ld_bytes_words(w, V.in + V.venc_off[job], 8); merlin_append_words(s, "V", 1, w, 8);
@@ -282,30 +286,30 @@ ZKP_HD inline void step_vtranscript(const VfyView& V, uint32_t job, Strobe& s) {
     merlin_append_scalar(s, "e_blinding", 10, r_eb);
     const sc wch = merlin_challenge_scalar(s, "w", 1);
     merlin_append_bytes(s, "dom-sep", 7, "ipp v1", 6);
-    merlin_append_u64(s, "n", 1, BP_N);
+    merlin_append_u64(s, "n", 1, n);
     sc u[6];
-    for (uint32_t j = 0; j < 6; j++) {
+    for (uint32_t j = 0; j < lg; j++) {
         ld_bytes_words(w, pr + 224 + 64 * j, 8); merlin_append_words(s, "L", 1, w, 8);
         ld_bytes_words(w, pr + 224 + 64 * j + 32, 8); merlin_append_words(s, "R", 1, w, 8);
         u[j] = merlin_challenge_scalar(s, "u", 1);
     }
     const sc c = merlin_challenge_scalar(s, "libzkp-amd batch weight", 23);   // folds the two equations; not part of the proof
-    // one inversion for y, u_0..u_5 (Montgomery's trick)
+    // one inversion for y, u_0..u_{lg-1} (Montgomery's trick)
     sc pre[7]; sc run = y;
     pre[0] = sc_one();
-    for (uint32_t j = 0; j < 6; j++) { pre[j + 1] = run; run = sc_mul(run, u[j]); }
+    for (uint32_t j = 0; j < lg; j++) { pre[j + 1] = run; run = sc_mul(run, u[j]); }
     sc inv = sc_invert(run);
     sc uinv[6];
-    for (int j = 5; j >= 0; j--) { uinv[j] = sc_mul(inv, pre[j + 1]); inv = sc_mul(inv, u[j]); }
+    for (int j = (int)lg - 1; j >= 0; j--) { uinv[j] = sc_mul(inv, pre[j + 1]); inv = sc_mul(inv, u[j]); }
     const sc yinv = inv;
     const sc t_x = sc_from_raw256(r_tx), t_xb = sc_from_raw256(r_txb), e_bl = sc_from_raw256(r_eb), a = sc_from_raw256(r_a), b = sc_from_raw256(r_b);
     const sc zz = sc_mul(z, z), xx = sc_mul(x, x);
     sc sum_y = sc_zero(), yp = sc_one();
-    for (uint32_t i = 0; i < BP_N; i++) { sum_y = sc_add(sum_y, yp); yp = sc_mul(yp, y); }
-    const sc delta = sc_sub(sc_mul(sc_sub(z, zz), sum_y), sc_mul(sc_mul(zz, z), sc_from_u64(~0ull)));
+    for (uint32_t i = 0; i < n; i++) { sum_y = sc_add(sum_y, yp); yp = sc_mul(yp, y); }
+    const sc delta = sc_sub(sc_mul(sc_sub(z, zz), sum_y), sc_mul(sc_mul(zz, z), sc_from_u64(lg >= 6 ? ~0ull : (1ull << n) - 1)));   // <1, 2^n> = 2^n - 1
     st_sc(V.scal, VS_Z, job, M, z); st_sc(V.scal, VS_ZZ, job, M, zz); st_sc(V.scal, VS_YINV, job, M, yinv);
     st_sc(V.scal, VS_A, job, M, a); st_sc(V.scal, VS_B, job, M, b);
-    for (uint32_t j = 0; j < 6; j++) { st_sc(V.scal, VS_U + j, job, M, u[j]); st_sc(V.scal, VS_UINV + j, job, M, uinv[j]); }
+    for (uint32_t j = 0; j < lg; j++) { st_sc(V.scal, VS_U + j, job, M, u[j]); st_sc(V.scal, VS_UINV + j, job, M, uinv[j]); }
     // generator coefficients of B and B~
     st_digits(V.digits, BASE_B, job, M, sc_add(sc_mul(wch, sc_sub(t_x, sc_mul(a, b))), sc_mul(c, sc_sub(t_x, delta))));
     st_digits(V.digits, BASE_BB, job, M, sc_sub(sc_mul(c, t_xb), e_bl));
@@ -316,20 +320,21 @@ ZKP_HD inline void step_vtranscript(const VfyView& V, uint32_t job, Strobe& s) {
     st_sc(V.vscal, VP_S, job, M, sc_to_raw(x));
     st_sc(V.vscal, VP_T1, job, M, sc_to_raw(sc_neg(sc_mul(c, x))));
     st_sc(V.vscal, VP_T2, job, M, sc_to_raw(sc_neg(sc_mul(c, xx))));
-    for (uint32_t j = 0; j < 6; j++) {
+    for (uint32_t j = 0; j < lg; j++) {
         st_sc(V.vscal, VP_L + j, job, M, sc_to_raw(sc_mul(u[j], u[j])));
         st_sc(V.vscal, VP_R + j, job, M, sc_to_raw(sc_mul(uinv[j], uinv[j])));
     }
 }
 
-// ---- step 3: coefficients of G_i and H_i.  thread = (i, job)
+// ---- step 3: coefficients of G_i and H_i.  thread = (i, job), i in [0, 64): generators past the job's width keep zero digits
 ZKP_HD inline void step_vscalars(const VfyView& V, uint32_t i, uint32_t job) {
     if (V.bad[job]) return;
-    const uint32_t M = V.M;
-    sc s_i = sc_one(), s_r = sc_one();                 // s_i and s_{63-i}
-    for (uint32_t j = 0; j < 6; j++) {
+    const uint32_t M = V.M, lg = V.lgn[job];
+    if (i >> lg) return;
+    sc s_i = sc_one(), s_r = sc_one();                 // s_i and s_{n-1-i}
+    for (uint32_t j = 0; j < lg; j++) {
         const sc u = ld_sc(V.scal, VS_U + j, job, M), ui = ld_sc(V.scal, VS_UINV + j, job, M);
-        const bool bit = (i >> (5 - j)) & 1u;
+        const bool bit = (i >> (lg - 1 - j)) & 1u;
         s_i = sc_mul(s_i, bit ? u : ui);
         s_r = sc_mul(s_r, bit ? ui : u);
     }
@@ -345,7 +350,7 @@ ZKP_HD inline void step_vscalars(const VfyView& V, uint32_t i, uint32_t job) {
 ZKP_HD inline void step_vvarbase(const VfyView& V, uint32_t p, uint32_t job) {
     const uint32_t M = V.M;
     ge r = ge_identity();
-    if (!V.bad[job]) {
+    if (!V.bad[job] && vpoint_present(p, V.lgn[job])) {
         const ge pt = ld_ge(V.pts, p, job, M);
         r = p == VP_A ? pt : ge_scalarmult_raw(pt, ld_sc(V.vscal, p, job, M));
     }

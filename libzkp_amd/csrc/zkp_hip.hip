@@ -29,10 +29,10 @@
 
 // ================================================================================================ kernels
 
-__global__ void __launch_bounds__(TB) k_build_range(JobBuf J, uint32_t n, const uint64_t* value, const uint64_t* mn, const uint64_t* mx,
+__global__ void __launch_bounds__(TB) k_build_range(JobBuf J, uint32_t n, const uint64_t* value, const uint64_t* mn, const uint64_t* mx, uint32_t lg,
                                                     uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
     const uint32_t op = blockIdx.x * TB + threadIdx.x;
-    if (op < n) step_build_range(J, op, value, mn, mx, out, stride, out_len, status);
+    if (op < n) step_build_range(J, op, value, mn, mx, lg, out, stride, out_len, status);
 }
 __global__ void __launch_bounds__(TB) k_ctask(CtView T) {
     const uint32_t c = blockIdx.x * TB + threadIdx.x;
@@ -151,6 +151,22 @@ int fail(int code, const std::string& msg) { t_err = msg; return code; }
         if (e_ != hipSuccess) return fail(ZKP_HIP_E_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Per-call device buffers: released when the call returns, on every path (HIP_TRY returns early on errors).
+struct DevScope {
+    std::vector<void*> owned;
+    DevScope() = default;
+    DevScope(const DevScope&) = delete;
+    DevScope& operator=(const DevScope&) = delete;
+    ~DevScope() { for (void* q : owned) (void)hipFree(q); }
+    template <class T> hipError_t alloc(T** out, size_t bytes) {
+        void* q = nullptr;
+        const hipError_t e = hipMalloc(&q, bytes ? bytes : 1);
+        if (e == hipSuccess) owned.push_back(q);
+        *out = static_cast<T*>(q);
+        return e;
+    }
+};
+
 struct DevLayout {
     uint16_t *slot_base = nullptr, *chunk_begin = nullptr, *chunk_win0 = nullptr, *chunk_nwin = nullptr, *target_chunk_begin = nullptr;
     uint8_t* slot_nwin = nullptr;
@@ -169,7 +185,7 @@ struct SubBatch {
     hipEvent_t side_go = nullptr, side_done = nullptr;
     bool used = false;                             // `done` has been recorded at least once
     void* ws = nullptr;
-    uint32_t capM = 0, capC = 0;
+    uint32_t capM = 0, capC = 0, cap_chunks = 0;
 };
 constexpr uint32_t NSLOTS = 2;      // device-pointer calls alternate between two sets of streams + workspace, so a caller that
                                     // feeds batches from two of its own streams keeps two batches in flight (bench.py --pipeline 2)
@@ -180,7 +196,11 @@ struct Ctx {
     int num_cu = 256, msm_blocks_per_cu = 3;
     hipStream_t stream = nullptr;
     uint32_t* d_table = nullptr;
-    LayoutSet p1, p2, rd[6], ct;
+    // MSM chunkings: phase 1 and the inner-product rounds depend on the proofs' bit width n = 8 << w (w = 0..3); the
+    // 64-bit family is built at init, narrower ones on first use
+    struct Family { LayoutSet p1, rd[6]; bool ready = false; };
+    Family fam[4];
+    LayoutSet p2, ct;
     uint32_t max_chunks = 0;
     std::vector<SubBatch> sub;          // [slot * nsub + h]
     uint32_t nsub = 1, next_slot = 0;
@@ -264,6 +284,23 @@ const DevLayout& pick_layout(const LayoutSet& S, uint32_t rows) {
     return S.cand[best < S.cand.size() ? best : 0];
 }
 
+// chunkings of the launches whose generator set depends on the bit width (lg = log2 n, 3..6)
+int ensure_family(uint32_t lg) {
+    Ctx::Family& F = g.fam[lg - 3];
+    if (F.ready) return 0;
+    int rc;
+    if ((rc = upload_set(F.p1, targets_phase1(1u << lg)))) return rc;
+    for (uint32_t r = 0; r < lg; r++) if ((rc = upload_set(F.rd[r], targets_round(r, 1u << lg)))) return rc;
+    if (F.p1.max_chunks > g.max_chunks) g.max_chunks = F.p1.max_chunks;
+    for (uint32_t r = 0; r < lg; r++) if (F.rd[r].max_chunks > g.max_chunks) g.max_chunks = F.rd[r].max_chunks;
+    F.ready = true;
+    return 0;
+}
+bool bits_to_lg(uint32_t n_bits, uint32_t* lg) {     // RangeProof::prove_single accepts 8, 16, 32, 64 (InvalidBitsize otherwise)
+    for (uint32_t k = 3; k <= 6; k++) if (n_bits == (1u << k)) { *lg = k; return true; }
+    return false;
+}
+
 int init_locked(int device) {
     if (g.ready) {
         if (device != g.device) return fail(ZKP_HIP_E_ARGUMENT, "zkp_hip_init: already initialised on another device");
@@ -299,12 +336,10 @@ int init_locked(int device) {
     HIP_TRY(hipMemcpy(g.d_table, tab.data(), words * 4, hipMemcpyHostToDevice));
     int rc;
     g.max_chunks = 0;
-    if ((rc = upload_set(g.p1, targets_phase1()))) return rc;
     if ((rc = upload_set(g.p2, targets_phase2()))) return rc;
-    for (uint32_t r = 0; r < 6; r++) if ((rc = upload_set(g.rd[r], targets_round(r)))) return rc;
     if ((rc = upload_set(g.ct, targets_ctask()))) return rc;
-    g.max_chunks = g.p1.max_chunks > g.p2.max_chunks ? g.p1.max_chunks : g.p2.max_chunks;
-    for (uint32_t r = 0; r < 6; r++) if (g.rd[r].max_chunks > g.max_chunks) g.max_chunks = g.rd[r].max_chunks;
+    g.max_chunks = g.p2.max_chunks;
+    if ((rc = ensure_family(6))) return rc;
     uint32_t ns = g_subbatches; if (ns < 1) ns = 1; if (ns > 8) ns = 8;
     g.nsub = ns;
     g.sub.resize((size_t)NSLOTS * ns);
@@ -361,12 +396,12 @@ size_t carve(uint8_t* base, uint32_t M, uint32_t C, uint32_t max_chunks, Ws* w) 
 }
 
 int ensure_workspace(SubBatch& sb, uint32_t M, uint32_t C) {
-    if (M <= sb.capM && C <= sb.capC && sb.ws) return 0;
+    if (M <= sb.capM && C <= sb.capC && g.max_chunks <= sb.cap_chunks && sb.ws) return 0;
     if (sb.ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(sb.ws)); sb.ws = nullptr; }
     const uint32_t nm = M > sb.capM ? M : sb.capM, nc = C > sb.capC ? C : sb.capC;
     const size_t bytes = carve(nullptr, nm, nc, g.max_chunks, nullptr);
     HIP_TRY(hipMalloc(&sb.ws, bytes));
-    sb.capM = nm; sb.capC = nc;
+    sb.capM = nm; sb.capC = nc; sb.cap_chunks = g.max_chunks;
     return 0;
 }
 
@@ -405,6 +440,8 @@ int msm_and_encode(const LayoutSet& S, uint32_t rows, const uint32_t* digits, ui
 int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st, SubBatch& lane) {
     int rc;
     const dim3 gj((M + TB - 1) / TB), gw((M + TW - 1) / TW);
+    const uint32_t n = w.V.n, lg = w.V.lg;
+    const Ctx::Family& F = g.fam[lg - 3];
     // The commitment tasks (one small MSM, one inverse-square-root chain on C/64 waves) depend on nothing the proofs compute:
     // they go to a side stream and overlap the tape / first MSM instead of standing in front of them.
     const bool forked = C != 0 && M != 0;
@@ -416,18 +453,18 @@ int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st, SubBatch& 
         if (forked) HIP_TRY(hipEventRecord(lane.side_done, cs));
     }
     if (M == 0) { HIP_TRY(hipGetLastError()); return 0; }
-    k_tape<<<dim3(gj.x, TAPE_SLOTS + 1), TB, 0, st>>>(w.V);
-    if ((rc = msm_and_encode(g.p1, M, w.V.d1, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
+    k_tape<<<dim3(gj.x, tape_slots(n) + 1), TB, 0, st>>>(w.V);
+    if ((rc = msm_and_encode(F.p1, M, w.V.d1, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
     k_transcript1<<<gw, TW, 0, st>>>(w.V);
-    k_poly<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V);
+    k_poly<<<dim3(gj.x, n), TB, 0, st>>>(w.V);
     k_poly_sum<<<(M + 7) / 8, TW, 0, st>>>(w.V);
     if ((rc = msm_and_encode(g.p2, M, w.V.d2, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
     k_transcript2<<<gw, TW, 0, st>>>(w.V);
-    k_lr_init<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V);
-    for (uint32_t r = 0; r < 6; r++) {
-        k_round_prep<<<dim3(gj.x, BP_N), TB, 0, st>>>(w.V, r);
+    k_lr_init<<<dim3(gj.x, n), TB, 0, st>>>(w.V);
+    for (uint32_t r = 0; r < lg; r++) {
+        k_round_prep<<<dim3(gj.x, n), TB, 0, st>>>(w.V, r);
         k_round_sum<<<gw, TW, 0, st>>>(w.V, r);
-        if ((rc = msm_and_encode(g.rd[r], M, w.V.dr, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
+        if ((rc = msm_and_encode(F.rd[r], M, w.V.dr, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
         k_transcript_round<<<gw, TW, 0, st>>>(w.V, r);
     }
     if (forked) HIP_TRY(hipStreamWaitEvent(st, lane.side_done, 0));
@@ -443,13 +480,14 @@ __global__ void k_any_failed(const int32_t* status, uint32_t n, int* flag) {
 // Ops are independent, so the batch is cut into contiguous sub-batches that run the whole kernel sequence on their
 // own streams: while one sub-batch is in a latency-bound per-proof step (transcript, inversion, encoding) the other's
 // MSM keeps the CUs busy.  `st` (the caller's stream) is forked into the sub-streams and joined again.
-int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_t* d_min, const uint64_t* d_max,
+int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_t* d_min, const uint64_t* d_max, uint32_t lg,
                               const uint8_t* d_seeds, uint8_t* d_out, uint64_t stride, uint32_t* d_out_len, int32_t* d_status,
                               hipStream_t st, int* any_failed) {
     if (n == 0) { if (any_failed) *any_failed = 0; return 0; }
     if (n > (1u << 30)) return fail(ZKP_HIP_E_ARGUMENT, "batch too large");
-    if (stride < RANGE_PROOF_BYTES) return fail(ZKP_HIP_E_ARGUMENT, "stride must be >= 1478");
+    if (stride < range_envelope_bytes(lg)) return fail(ZKP_HIP_E_ARGUMENT, "stride is smaller than the proof (1478 bytes for n_bits = 64)");
     int rc;
+    if ((rc = ensure_family(lg))) return rc;
     uint32_t nsub = g.nsub;
     if (n < 512) nsub = 1;                       // small batches: one stream
     const uint64_t per = (n + nsub - 1) / nsub;
@@ -463,10 +501,11 @@ int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_
         const uint32_t C = (uint32_t)(hi - lo), M = 2 * C;
         if ((rc = ensure_workspace(sb, M, C))) return rc;
         Ws w; carve((uint8_t*)sb.ws, M, C, g.max_chunks, &w);
+        w.V.n = 1u << lg; w.V.lg = lg;
         w.V.seeds = reinterpret_cast<const uint32_t*>(d_seeds + 32 * lo); w.T.seeds = w.V.seeds;
         w.V.out = d_out + lo * stride;
         HIP_TRY(hipStreamWaitEvent(sb.stream, first.start, 0));        // (the slot's previous batch is ahead of this one on sb.stream)
-        k_build_range<<<(C + TB - 1) / TB, TB, 0, sb.stream>>>(w.J, C, d_value + lo, d_min + lo, d_max + lo, w.V.out, stride, d_out_len + lo, d_status + lo);
+        k_build_range<<<(C + TB - 1) / TB, TB, 0, sb.stream>>>(w.J, C, d_value + lo, d_min + lo, d_max + lo, lg, w.V.out, stride, d_out_len + lo, d_status + lo);
         if ((rc = run_pipeline(w, M, C, sb.stream, sb))) return rc;
         HIP_TRY(hipEventRecord(sb.done, sb.stream)); sb.used = true;
         HIP_TRY(hipStreamWaitEvent(st, sb.done, 0));
@@ -497,18 +536,20 @@ struct HostJobs {
 };
 
 // out: host buffer already holding every framing byte; proofs and commitments are filled in by the device
-int run_host_jobs(const HostJobs& H, const uint8_t* seeds, size_t nseeds, uint8_t* out, size_t out_bytes) {
+int run_host_jobs(const HostJobs& H, const uint8_t* seeds, size_t nseeds, uint8_t* out, size_t out_bytes, uint32_t lg = 6) {
     const uint32_t M = (uint32_t)H.v.size(), C = (uint32_t)H.ct_v.size();
     if (M == 0 && C == 0) return 0;
     int rc;
+    if ((rc = ensure_family(lg))) return rc;
     SubBatch& sb = g.sub[0];
     hipStream_t st = g.stream;
     if (sb.used) HIP_TRY(hipStreamWaitEvent(st, sb.done, 0));          // an asynchronous device-pointer call may still own this workspace
     if ((rc = ensure_workspace(sb, M ? M : 1, C ? C : 1))) return rc;
     Ws w; carve((uint8_t*)sb.ws, M ? M : 1, C ? C : 1, g.max_chunks, &w);
-    w.V.M = M; w.T.C = C;
+    w.V.M = M; w.T.C = C; w.V.n = 1u << lg; w.V.lg = lg;
+    DevScope mem;
     uint8_t *d_seeds = nullptr, *d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_seeds, 32 * nseeds)); HIP_TRY(hipMalloc(&d_out, out_bytes));
+    HIP_TRY(mem.alloc(&d_seeds, 32 * nseeds)); HIP_TRY(mem.alloc(&d_out, out_bytes));
     HIP_TRY(hipMemcpyAsync(d_seeds, seeds, 32 * nseeds, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_out, out, out_bytes, hipMemcpyHostToDevice, st));
 #define UP(dst, vec) do { if (!(vec).empty()) HIP_TRY(hipMemcpyAsync((void*)(dst), (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, st)); } while (0)
@@ -520,9 +561,8 @@ int run_host_jobs(const HostJobs& H, const uint8_t* seeds, size_t nseeds, uint8_
     rc = run_pipeline(w, M, C, st, sb);
     if (rc == 0) {
         HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
     }
-    (void)hipFree(d_seeds); (void)hipFree(d_out);
+    HIP_TRY(hipStreamSynchronize(st));          // nothing may still be using the per-call buffers when `mem` goes
     return rc;
 }
 
@@ -571,8 +611,8 @@ void zkp_hip_shutdown(void) {
         (void)hipEventDestroy(sb.start); (void)hipEventDestroy(sb.done); (void)hipEventDestroy(sb.side_go); (void)hipEventDestroy(sb.side_done);
     }
     (void)hipFree(g.d_table);
-    free_set(g.p1); free_set(g.p2); free_set(g.ct);
-    for (auto& d : g.rd) free_set(d);
+    free_set(g.p2); free_set(g.ct);
+    for (auto& F : g.fam) { free_set(F.p1); for (auto& d : F.rd) free_set(d); }
     for (auto& e : g.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     (void)hipStreamDestroy(g.stream);
     g = Ctx();
@@ -599,24 +639,26 @@ int zkp_hip_profile_read(double* msm_ms, uint64_t* msm_launches, uint64_t* msm_p
 int zkp_hip_prove_range_batch_device(uint64_t n, const uint64_t* d_value, const uint64_t* d_min, const uint64_t* d_max, uint32_t n_bits,
                                      const uint8_t* d_seeds, uint8_t* d_out, uint64_t stride, uint32_t* d_out_len, int32_t* d_status,
                                      void* stream, int* any_failed) {
-    if (n_bits != 64) return fail(ZKP_HIP_E_UNSUPPORTED, "only n_bits = 64 is implemented (what prove_range uses)");
+    uint32_t lg;
+    if (!bits_to_lg(n_bits, &lg)) return fail(ZKP_HIP_E_UNSUPPORTED, "n_bits must be 8, 16, 32 or 64");
     if (!d_seeds) return fail(ZKP_HIP_E_ARGUMENT, "device entry point needs seeds");
     std::lock_guard<std::mutex> lk(g_mu);
     int rc = init_locked(g.ready ? g.device : 0);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(g.device));
     hipStream_t st = stream ? (hipStream_t)stream : g.stream;
-    rc = prove_range_device_locked(n, d_value, d_min, d_max, d_seeds, d_out, stride, d_out_len, d_status, st, any_failed);
+    rc = prove_range_device_locked(n, d_value, d_min, d_max, lg, d_seeds, d_out, stride, d_out_len, d_status, st, any_failed);
     if (rc) return rc;
     return (any_failed && *any_failed) ? 1 : 0;
 }
 
 int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* min, const uint64_t* max, uint32_t n_bits,
                               const uint8_t* seeds, uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
-    if (n_bits != 64) return fail(ZKP_HIP_E_UNSUPPORTED, "only n_bits = 64 is implemented (what prove_range uses)");
+    uint32_t lg;
+    if (!bits_to_lg(n_bits, &lg)) return fail(ZKP_HIP_E_UNSUPPORTED, "n_bits must be 8, 16, 32 or 64");
     if (n == 0) return 0;
     if (!value || !min || !max || !out || !out_len || !status) return fail(ZKP_HIP_E_ARGUMENT, "null pointer argument");
-    if (stride < RANGE_PROOF_BYTES) return fail(ZKP_HIP_E_ARGUMENT, "stride must be >= 1478");
+    if (stride < range_envelope_bytes(lg)) return fail(ZKP_HIP_E_ARGUMENT, "stride is smaller than the proof (1478 bytes for n_bits = 64)");
     std::vector<uint8_t> fresh;
     if (!seeds) { int rc0 = fresh_seeds(fresh, n); if (rc0) return rc0; seeds = fresh.data(); }   // bulletproofs.rs:82-87
     std::lock_guard<std::mutex> lk(g_mu);
@@ -624,16 +666,17 @@ int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t*
     if (rc) return rc;
     HIP_TRY(hipSetDevice(g.device));
     hipStream_t st = g.stream;
+    DevScope mem;
     uint64_t *d_in = nullptr; uint8_t *d_seeds = nullptr, *d_out = nullptr; uint32_t* d_len = nullptr; int32_t* d_status = nullptr;
-    HIP_TRY(hipMalloc(&d_in, 24 * n)); HIP_TRY(hipMalloc(&d_seeds, 32 * n)); HIP_TRY(hipMalloc(&d_out, stride * n));
-    HIP_TRY(hipMalloc(&d_len, 4 * n)); HIP_TRY(hipMalloc(&d_status, 4 * n));
+    HIP_TRY(mem.alloc(&d_in, 24 * n)); HIP_TRY(mem.alloc(&d_seeds, 32 * n)); HIP_TRY(mem.alloc(&d_out, stride * n));
+    HIP_TRY(mem.alloc(&d_len, 4 * n)); HIP_TRY(mem.alloc(&d_status, 4 * n));
     HIP_TRY(hipMemcpyAsync(d_in, value, 8 * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_in + n, min, 8 * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_in + 2 * n, max, 8 * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_seeds, seeds, 32 * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_out, 0, stride * n, st));
     int any = 0;
-    rc = prove_range_device_locked(n, d_in, d_in + n, d_in + 2 * n, d_seeds, d_out, stride, d_len, d_status, st, &any);
+    rc = prove_range_device_locked(n, d_in, d_in + n, d_in + 2 * n, lg, d_seeds, d_out, stride, d_len, d_status, st, &any);
     if (rc == 0) {
         HIP_TRY(hipMemcpyAsync(out, d_out, stride * n, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(out_len, d_len, 4 * n, hipMemcpyDeviceToHost, st));
@@ -642,10 +685,12 @@ int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t*
         // a failed item leaves no proof bytes behind (reference returns Err, never a partial Vec)
         for (uint64_t i = 0; i < n; i++) if (status[i] != 0) memset(out + i * stride, 0, stride);
     }
-    (void)hipFree(d_in); (void)hipFree(d_seeds); (void)hipFree(d_out); (void)hipFree(d_len); (void)hipFree(d_status);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(st); return rc; }
     return any ? 1 : 0;
 }
+
+uint64_t zkp_hip_range_proof_bytes(uint32_t n_bits) { uint32_t lg; return bits_to_lg(n_bits, &lg) ? range_envelope_bytes(lg) : 0; }
+uint64_t zkp_hip_threshold_proof_bytes(uint32_t n_bits) { uint32_t lg; return bits_to_lg(n_bits, &lg) ? 10 + 8 + 4 + 4 + rp_bytes(lg) + 32 + 32 : 0; }
 
 uint64_t zkp_hip_consistency_proof_bytes(uint32_t count) {
     if (count == 0) return 0;
@@ -654,11 +699,14 @@ uint64_t zkp_hip_consistency_proof_bytes(uint32_t count) {
 
 int zkp_hip_prove_threshold_batch(uint64_t n, const uint64_t* values, const uint32_t* counts, const uint64_t* thresholds, uint32_t n_bits,
                                   const uint8_t* seeds, uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
-    if (n_bits != 64) return fail(ZKP_HIP_E_UNSUPPORTED, "only n_bits = 64 is implemented (what prove_threshold uses)");
+    uint32_t lg;
+    if (!bits_to_lg(n_bits, &lg)) return fail(ZKP_HIP_E_UNSUPPORTED, "n_bits must be 8, 16, 32 or 64");
     if (n == 0) return 0;
     if (!values || !counts || !thresholds || !out || !out_len || !status) return fail(ZKP_HIP_E_ARGUMENT, "null pointer argument");
-    const uint64_t PB = 762;
-    if (stride < PB) return fail(ZKP_HIP_E_ARGUMENT, "stride must be >= 762");
+    const uint32_t RP = rp_bytes(lg);
+    const uint64_t PB = 10 + 8 + 4 + 4 + RP + 32 + 32;                      // 762 for n_bits = 64
+    const uint64_t max_diff = lg >= 6 ? ~0ull : (1ull << (1u << lg)) - 1;   // bulletproofs.rs:330-336
+    if (stride < PB) return fail(ZKP_HIP_E_ARGUMENT, "stride is smaller than the proof (762 bytes for n_bits = 64)");
     std::vector<uint8_t> fresh;
     if (!seeds) { int rc = fresh_seeds(fresh, n); if (rc) return rc; seeds = fresh.data(); }
     HostJobs H; int any = 0; size_t pos = 0;
@@ -669,19 +717,20 @@ int zkp_hip_prove_threshold_batch(uint64_t n, const uint64_t* values, const uint
         for (uint32_t k = 0; k < counts[i] && ok; k++) { const uint64_t x = values[pos + k]; if (sum + x < sum) ok = false; sum += x; }
         pos += counts[i];
         if (ok && sum < thresholds[i]) ok = false;
+        if (ok && sum - thresholds[i] > max_diff) ok = false;
         status[i] = ok ? ZKP_HIP_OK : ZKP_HIP_INVALID_INPUT; out_len[i] = ok ? (uint32_t)PB : 0; any |= !ok;
         if (!ok) continue;
         uint8_t* o = out + i * stride; const uint64_t base = i * stride;
-        o[0] = 2; o[1] = 3; put_le_host(o + 2, 8 + 4 + 4 + RP_BYTES + 32, 4); put_le_host(o + 6, 32, 4);
-        put_le_host(o + 10, thresholds[i], 8); put_le_host(o + 18, 64, 4); put_le_host(o + 22, RP_BYTES, 4);
-        H.add_job(sum - thresholds[i], (uint32_t)i, 0, 0, -1, KIND_THRESHOLD, base + 26, base + 26 + RP_BYTES);
-        H.add_commit(sum, (uint32_t)i, 0, base + 26 + RP_BYTES + 32);
+        o[0] = 2; o[1] = 3; put_le_host(o + 2, 8 + 4 + 4 + RP + 32, 4); put_le_host(o + 6, 32, 4);
+        put_le_host(o + 10, thresholds[i], 8); put_le_host(o + 18, n_bits, 4); put_le_host(o + 22, RP, 4);
+        H.add_job(sum - thresholds[i], (uint32_t)i, 0, 0, -1, KIND_THRESHOLD, base + 26, base + 26 + RP);
+        H.add_commit(sum, (uint32_t)i, 0, base + 26 + RP + 32);
     }
     std::lock_guard<std::mutex> lk(g_mu);
     int rc = init_locked(g.ready ? g.device : 0);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(g.device));
-    if ((rc = run_host_jobs(H, seeds, n, out, stride * n))) return rc;
+    if ((rc = run_host_jobs(H, seeds, n, out, stride * n, lg))) return rc;
     return any;
 }
 

@@ -33,17 +33,19 @@ static void run_reduce(const MsmLayout& L, uint32_t rows, const std::vector<uint
 extern "C" {
 void emul_generator(uint32_t idx, uint32_t enc[8]) { ge g[NBASE]; host_generators(g); ge_ristretto_encode(enc, g[idx]); }
 
-// same contract as zkp_hip_prove_range_batch (include/libzkp_hip.h) with n_bits = 64
-int emul_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* mn, const uint64_t* mx, const uint8_t* seeds,
-                           uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status, uint32_t win_budget) {
+// same contract as zkp_hip_prove_range_batch (include/libzkp_hip.h)
+int emul_prove_range_batch_bits(uint64_t n, const uint64_t* value, const uint64_t* mn, const uint64_t* mx, uint32_t n_bits, const uint8_t* seeds,
+                                uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status, uint32_t win_budget) {
     ensure_table();
+    uint32_t lg = 0; while ((1u << lg) < n_bits) lg++;
+    if (lg < 3 || lg > 6 || (1u << lg) != n_bits) return -2;
     const uint32_t M = (uint32_t)(2 * n), C = (uint32_t)n;
     std::vector<uint64_t> v(M), poff(M), coff(M), ctv(C), ctoff(C);
     std::vector<uint32_t> six(M), pix(M), ctsix(C), ctbl(C);
     std::vector<int32_t> blp(M), blm(M);
     std::vector<uint8_t> kind(M);
     JobBuf J{v.data(), six.data(), pix.data(), blp.data(), blm.data(), kind.data(), poff.data(), coff.data(), ctv.data(), ctsix.data(), ctbl.data(), ctoff.data()};
-    for (uint32_t op = 0; op < n; op++) step_build_range(J, op, value, mn, mx, out, stride, out_len, status);
+    for (uint32_t op = 0; op < n; op++) step_build_range(J, op, value, mn, mx, lg, out, stride, out_len, status);
     std::vector<uint32_t> seedw(8 * n); memcpy(seedw.data(), seeds, 32 * n);
     auto words = [&](size_t k) { return std::vector<uint32_t>(k * 8 * M, 0xDEADBEEFu); };
     auto dwords = [&](size_t k) { return std::vector<uint32_t>(k * DIGW * M, 0xDEADBEEFu); };
@@ -51,7 +53,7 @@ int emul_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* mn
     auto tape = words(TAPE_SLOTS), gamma = words(1), yinv = words(64), ypq = words(32),
          r0 = words(64), r1 = words(64), pp = words(192), ab = words(256), gh = words(128), scal = words(SC_NUM), enc = words(3);
     std::vector<uint32_t> tstate((size_t)52 * M);
-    BpView V; V.M = M; V.v = v.data(); V.seed_ix = six.data(); V.proof_ix = pix.data(); V.bl_plus = blp.data(); V.bl_minus = blm.data(); V.kind = kind.data();
+    BpView V; V.M = M; V.n = n_bits; V.lg = lg; V.v = v.data(); V.seed_ix = six.data(); V.proof_ix = pix.data(); V.bl_plus = blp.data(); V.bl_minus = blm.data(); V.kind = kind.data();
     V.seeds = seedw.data(); V.proof_off = poff.data(); V.commit_off = coff.data(); V.out = out;
     V.tape = tape.data(); V.gamma = gamma.data(); V.d1 = d1.data(); V.d2 = d2.data(); V.dr = dr.data(); V.yinvpow = yinv.data(); V.ypq = ypq.data();
     V.r0 = r0.data(); V.r1 = r1.data(); V.pp = pp.data(); V.ab = ab.data(); V.gh = gh.data(); V.scal = scal.data(); V.tstate = tstate.data(); V.enc = enc.data();
@@ -66,25 +68,29 @@ int emul_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* mn
     MsmLayout Lc = even ? make_layout_even(targets_ctask(), nch) : layout_ctask(win_budget);
     run_msm(Lc, C, ctd.data(), partial); run_reduce(Lc, C, partial, ctenc.data(), ctoff.data(), out);
 
-    for (uint32_t slot = 0; slot <= TAPE_SLOTS; slot++) for (uint32_t j = 0; j < M; j++) step_tape(V, slot, j);
-    MsmLayout L1 = even ? make_layout_even(targets_phase1(), nch) : layout_phase1(win_budget);
+    for (uint32_t slot = 0; slot <= tape_slots(n_bits); slot++) for (uint32_t j = 0; j < M; j++) step_tape(V, slot, j);
+    MsmLayout L1 = even ? make_layout_even(targets_phase1(n_bits), nch) : layout_phase1(win_budget, n_bits);
     run_msm(L1, M, V.d1, partial); run_reduce(L1, M, partial, V.enc, nullptr, nullptr);
     for (uint32_t j = 0; j < M; j++) step_transcript1(V, j, s);
-    for (uint32_t i = 0; i < BP_N; i++) for (uint32_t j = 0; j < M; j++) step_poly(V, i, j);
+    for (uint32_t i = 0; i < n_bits; i++) for (uint32_t j = 0; j < M; j++) step_poly(V, i, j);
     for (uint32_t j = 0; j < M; j++) step_poly_sum(V, j);
     MsmLayout L2 = even ? make_layout_even(targets_phase2(), nch) : layout_phase2(win_budget);
     run_msm(L2, M, V.d2, partial); run_reduce(L2, M, partial, V.enc, nullptr, nullptr);
     for (uint32_t j = 0; j < M; j++) step_transcript2(V, j, s);
-    for (uint32_t i = 0; i < BP_N; i++) for (uint32_t j = 0; j < M; j++) step_lr_init(V, i, j);
-    for (uint32_t r = 0; r < 6; r++) {
-        for (uint32_t i = 0; i < BP_N; i++) for (uint32_t j = 0; j < M; j++) step_round_prep(V, r, i, j);
+    for (uint32_t i = 0; i < n_bits; i++) for (uint32_t j = 0; j < M; j++) step_lr_init(V, i, j);
+    for (uint32_t r = 0; r < lg; r++) {
+        for (uint32_t i = 0; i < n_bits; i++) for (uint32_t j = 0; j < M; j++) step_round_prep(V, r, i, j);
         for (uint32_t j = 0; j < M; j++) step_round_sum(V, r, j);
-        MsmLayout Lr = even ? make_layout_even(targets_round(r), nch) : layout_round(r, win_budget);
+        MsmLayout Lr = even ? make_layout_even(targets_round(r, n_bits), nch) : layout_round(r, win_budget, n_bits);
         run_msm(Lr, M, V.dr, partial); run_reduce(Lr, M, partial, V.enc, nullptr, nullptr);
         for (uint32_t j = 0; j < M; j++) step_transcript_round(V, r, j, s);
     }
     int fail = 0; for (uint32_t op = 0; op < n; op++) fail |= status[op] != 0;
     return fail;
+}
+int emul_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* mn, const uint64_t* mx, const uint8_t* seeds,
+                           uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status, uint32_t win_budget) {
+    return emul_prove_range_batch_bits(n, value, mn, mx, 64, seeds, out, stride, out_len, status, win_budget);
 }
 
 // same contract as zkp_hip_verify_range_batch (include/libzkp_hip.h); nchunks = chunk count of the fixed-base part
@@ -93,10 +99,10 @@ int emul_verify_range_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, 
     ensure_table();
     const uint32_t M = (uint32_t)(2 * n);
     const MsmLayout L = make_layout_even(targets_verify(), nchunks);
-    std::vector<uint64_t> poff(M), voff(M); std::vector<uint8_t> kind(M); std::vector<int32_t> bad(M);
+    std::vector<uint64_t> poff(M), voff(M); std::vector<uint8_t> kind(M), lgn(M); std::vector<int32_t> bad(M);
     std::vector<uint32_t> pts((size_t)VP_NUM * GE_W * M), scal((size_t)VS_NUM * 8 * M), dig((size_t)NBASE * DIGW * M, 0), vs((size_t)VP_NUM * 8 * M, 0);
     std::vector<uint32_t> partial((size_t)(L.nchunks() + VP_NUM) * GE_W * M), enc((size_t)8 * M);
-    VfyView V{}; V.M = M; V.in = proofs; V.proof_off = poff.data(); V.venc_off = voff.data(); V.kind = kind.data(); V.bad = bad.data();
+    VfyView V{}; V.M = M; V.in = proofs; V.proof_off = poff.data(); V.venc_off = voff.data(); V.kind = kind.data(); V.lgn = lgn.data(); V.bad = bad.data();
     V.pts = pts.data(); V.scal = scal.data(); V.digits = dig.data(); V.vscal = vs.data(); V.partial = partial.data(); V.var_chunk0 = L.nchunks(); V.table = g_table.data();
     for (uint32_t i = 0; i < n; i++) step_vparse(V, i, proofs + stride * i, stride * i, lens[i] <= stride ? lens[i] : 0u, mins[i], maxs[i]);
     for (uint32_t p = 0; p < VP_NUM; p++) for (uint32_t j = 0; j < M; j++) step_vdecode(V, p, j);

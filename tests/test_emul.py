@@ -7,7 +7,7 @@ import numpy as np
 
 from oracle.py import bulletproofs as bp
 from oracle.py import merlin, ristretto as R
-from util import P, U64, oracle_prove, outputs, workload
+from util import P, U64, oracle_prove, oracle_verify, outputs, workload
 
 PP, LL = R.P, R.L
 
@@ -138,3 +138,38 @@ def test_steps_validation(emul):
     out, lens, st = outputs(n)
     rc = lib.emul_prove_range_batch(U64(n), P(v), P(mn), P(mx), P(seeds), P(out), U64(1478), P(lens), P(st), 128)
     assert rc == 1 and list(st) == [0, 1, 1] and list(lens) == [1478, 0, 0]
+
+
+def test_prover_steps_bit_widths(emul, oracle_c):
+    """prove_range_with_bits (range_proof.rs:16-27, bulletproofs.rs:112-178): 8/16/32-bit proofs through the same emulated
+    kernels give the oracle's bytes (C restatement, cross-checked against the Python one for one case)."""
+    import oracle.py.bulletproofs as obp
+    _, lib = emul
+    for bits in (8, 16, 32):
+        size = 1478 - 2 * 64 * (6 - bits.bit_length() + 1)
+        cap = 2**bits - 1
+        v = np.array([cap, 5, 0, 7, 300 if bits == 8 else 3], dtype=np.uint64)
+        mn = np.array([0, 5, 0, 3, 0], dtype=np.uint64)
+        mx = np.array([cap, 5 + cap, cap, 7, 300 if bits == 8 else 9], dtype=np.uint64)
+        if bits == 8:
+            mx[4] = 310                                              # value - min = 300 needs 9 bits: "range width exceeds 8-bit capacity"
+        n = len(v)
+        seeds = np.frombuffer(np.random.default_rng(bits).bytes(32 * n), dtype=np.uint8).copy()
+        out, lens, st = outputs(n)
+        rc = lib.emul_prove_range_batch_bits(U64(n), P(v), P(mn), P(mx), bits, P(seeds), P(out), U64(1478), P(lens), P(st), 10000 + 9)
+        o2, l2, s2 = outputs(n)
+        rc2 = oracle_c.zkp_oracle_prove_range_batch(U64(n), P(v), P(mn), P(mx), bits, P(seeds), P(o2), U64(1478), P(l2), P(s2), 4)
+        want_fail = bits == 8
+        assert rc == rc2 == (1 if want_fail else 0)
+        assert list(lens) == list(l2) == [size] * 4 + [0 if want_fail else size]
+        assert list(st != 0) == list(s2 != 0)
+        assert (out[st == 0] == o2[st == 0]).all()                   # (the C ABI wrapper clears the bytes of failed items)
+        allok, ok = oracle_verify(oracle_c, out, lens, mn, mx, threads=4)
+        assert list(ok) == [1] * 4 + [0 if want_fail else 1]
+        if bits == 8:
+            body, commit = obp._unwire(obp.prove_range_with_bounds_bits(int(v[0]), int(mn[0]), int(mx[0]), 8, seeds[:32].tobytes()))
+            env = bytes([2, 1]) + len(body).to_bytes(4, "little") + (32).to_bytes(4, "little") + body + commit   # proof/mod.rs:23-36
+            assert env == out[0, :size].tobytes()
+    out, lens, st = outputs(1)
+    one = np.array([1], dtype=np.uint64)
+    assert lib.emul_prove_range_batch_bits(U64(1), P(one), P(one), P(one), 12, P(np.zeros(32, dtype=np.uint8)), P(out), U64(1478), P(lens), P(st), 128) == -2

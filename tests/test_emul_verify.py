@@ -7,7 +7,7 @@ import random
 import numpy as np
 import pytest
 
-from util import P, oracle_prove, oracle_verify, workload
+from util import P, U64, oracle_prove, oracle_verify, outputs, workload
 
 
 @pytest.fixture(scope="module")
@@ -75,3 +75,32 @@ def test_verdicts_equal_oracle(emul, oracle_c):
     sw = out.copy(); sw[0, 30:1382], sw[2, 30:1382] = out[2, 30:1382], out[0, 30:1382]
     want = oracle_verify(oracle_c, sw, lens, mn, mx)[1]
     assert list(emul_verify(emul, sw, lens, mn, mx)) == list(want) and want[0] == 0 and want[2] == 0
+
+
+def test_verdicts_bit_widths(emul, oracle_c):
+    """Proofs made with prove_range_with_bits (8/16/32-bit generators; the width travels in the envelope,
+    bulletproofs.rs:163-164,211-216) mixed in one verification batch with 64-bit ones."""
+    rnd = random.Random(5)
+    rows, lens_all, mns, mxs = [], [], [], []
+    for bits in (8, 16, 32, 64):
+        cap = 2**bits - 1
+        v = np.array([cap, 3], dtype=np.uint64); mn = np.array([0, 1], dtype=np.uint64); mx = np.array([cap, 9], dtype=np.uint64)
+        seeds = np.frombuffer(np.random.default_rng(100 + bits).bytes(64), dtype=np.uint8).copy()
+        out, lens, st = outputs(2)
+        assert oracle_c.zkp_oracle_prove_range_batch(U64(2), P(v), P(mn), P(mx), bits, P(seeds), P(out), U64(1478), P(lens), P(st), 2) == 0
+        rows.append(out); lens_all.append(lens); mns.append(mn); mxs.append(mx)
+    out, lens, mn, mx = np.concatenate(rows), np.concatenate(lens_all), np.concatenate(mns), np.concatenate(mxs)
+    n = len(lens)
+    assert list(lens) == [1094, 1094, 1222, 1222, 1350, 1350, 1478, 1478]
+    assert list(emul_verify(emul, out, lens, mn, mx)) == [1] * n
+    cases = []
+    for pos in (26, 30, 40, 300, 500, 700, 1000):          # the width field, a length field, proof bytes
+        t = out.copy()
+        for i in range(n):
+            t[i, (pos + 13 * i) % int(lens[i])] ^= 1 << rnd.randrange(8)
+        cases.append(t)
+    t = out.copy(); t[0, 26] = 16; cases.append(t)         # claims another valid width than the proof was made for
+    for t in cases:
+        want = oracle_verify(oracle_c, t, lens, mn, mx)[1]
+        assert list(emul_verify(emul, t, lens, mn, mx)) == list(want)
+    assert sum(int(x) for t in cases for x in oracle_verify(oracle_c, t, lens, mn, mx)[1]) < len(cases) * n

@@ -75,7 +75,7 @@ def test_empty_batch_and_bad_arguments(hip):
     out, lens, st = outputs(1)
     assert hip.zkp_hip_prove_range_batch(0, P(z), P(z), P(z), 64, None, P(out), PROOF, P(lens), P(st)) == 0
     one = np.ones(1, dtype=np.uint64)
-    assert hip.zkp_hip_prove_range_batch(1, P(one), P(one), P(one), 8, None, P(out), PROOF, P(lens), P(st)) == -2
+    assert hip.zkp_hip_prove_range_batch(1, P(one), P(one), P(one), 12, None, P(out), PROOF, P(lens), P(st)) == -2
     assert "n_bits" in _native.last_error()
     assert hip.zkp_hip_prove_range_batch(1, P(one), P(one), P(one), 64, None, P(out), 100, P(lens), P(st)) == -3
 
