@@ -145,6 +145,68 @@ ZKP_HD_NOINLINE inline fq12 final_exponentiation(const fq12& f) {
     }
     return acc;
 }
+// ---- the same check with the hard part as an addition chain in x (BN parameter, p = 36x^4 + 36x^3 + 24x^2 + 6x + 1):
+// f -> f^(m (p^12 - 1)/r) with m = 2x(6x^2 + 3x + 1), which is 1 exactly when f^((p^12 - 1)/r) is (m is prime to r).  Three
+// 63-bit powers and the p, p^2, p^3 Frobenius maps replace the 761-bit power: ~190 squarings and ~100 products.
+// The p^j-power Frobenius conjugates the Fq2 coefficients (odd j) and maps w^k to gamma_{j,k} w^k.
+ZKP_HD inline fq2 fq2_conj(const fq2& a) { return fq2{a.c0, fq_neg(a.c1)}; }
+ZKP_HD_NOINLINE inline fq12 fq12_frob_odd(const fq12& a, int j) {      // j = 1 or 3
+    // gamma_{1,k} = xi^(k (p^1 - 1) / 6), k = 1..5: (c0, c1) raw words
+    static constexpr uint32_t G1[5][2][8] = {
+        {{0xdcc9e470u, 0xd60b35dau, 0x292f2176u, 0x5c521e08u, 0x76e68b60u, 0xe8b99fddu, 0x2865a7dfu, 0x1284b71cu},
+         {0x80f362acu, 0xca5cf05fu, 0x8eeec7e5u, 0x74799277u, 0x12150b8eu, 0xa6327cfeu, 0xb4fae7e6u, 0x246996f3u}},
+        {{0x176f553du, 0x99e39557u, 0xc2c3330cu, 0xb78cc310u, 0xf559b143u, 0x4c0bec3cu, 0x4f7911f7u, 0x2fb34798u},
+         {0x640fcba2u, 0x1665d51cu, 0x0b7c9dceu, 0x32ae2a1du, 0xd75a0794u, 0x4ba4cc8bu, 0x61ebae20u, 0x16c9e550u}},
+        {{0x71a0135au, 0xdc540146u, 0xa9c95998u, 0xdbaae0edu, 0xb6e2f9b9u, 0xdc5ec698u, 0x489af5dcu, 0x063cf305u},
+         {0x2623b0e3u, 0x82d37f63u, 0x8fa25bd2u, 0x21807dc9u, 0xec796f2bu, 0x0704b5a7u, 0xac41049au, 0x07c03cbcu}},
+        {{0x921ea762u, 0x848a1f55u, 0xbe94ec72u, 0xd33365f7u, 0x5a181e84u, 0x80f3c0b7u, 0x64eea801u, 0x05b54f5eu},
+         {0xcd2b8126u, 0xc13b4711u, 0x1bdec763u, 0x3685d2eau, 0x3b0b1c92u, 0x9f3a80b0u, 0xe7fd8aeeu, 0x2c145edbu}},
+        {{0xeab7692fu, 0x2ea2c810u, 0x55aa1bd3u, 0x425c459bu, 0xa4353ff4u, 0xe93a3661u, 0x4f798649u, 0x0183c1e7u},
+         {0x6e0c2c4bu, 0x24c6b8eeu, 0x678e2ac0u, 0xb080cb99u, 0xc7729f7du, 0xa27fb246u, 0x76fd0675u, 0x12acf2cau}}
+    };
+    // gamma_{3,k} = xi^(k (p^3 - 1) / 6), k = 1..5: (c0, c1) raw words
+    static constexpr uint32_t G3[5][2][8] = {
+        {{0x1ed4a67fu, 0xe86f7d39u, 0xbe55d24au, 0x894cb38du, 0xd0acaa90u, 0xefe9608cu, 0xcc82e4bbu, 0x19dc81cfu},
+         {0xf4c0c101u, 0x7694aa2bu, 0x97d439ecu, 0x7f03a5e3u, 0x3576139du, 0x06cbeee3u, 0x0be77d73u, 0x00abf8b6u}},
+        {{0x7bdcfb6du, 0x7b746ee8u, 0x5d6942d3u, 0x805ffd3du, 0x959f25acu, 0xbaff1c77u, 0xb755ef0au, 0x0856e078u},
+         {0xaaa586deu, 0x380cab2bu, 0x98ff2631u, 0x0fdf31bfu, 0xec26094fu, 0xa9f30e6du, 0xb3d1766fu, 0x04f1de41u}},
+        {{0x66dce9edu, 0x5fcc8ad0u, 0xbea870f4u, 0xbbd689a3u, 0xca9e5ea3u, 0xdbf17f1du, 0x9896aa4cu, 0x2a275b6du},
+         {0xb2594c64u, 0xb94d0cb3u, 0xd8cf6ebau, 0x7600ecc7u, 0x9507e932u, 0xb14b900eu, 0x34f09b8fu, 0x28a411b6u}},
+        {{0x3ccbf066u, 0x0e1a92bcu, 0x75b06bcbu, 0xe6330945u, 0xb5b2444eu, 0x19bee0f7u, 0x11c08dabu, 0x0bc58c66u},
+         {0x730c239fu, 0x5fe3ed9du, 0x737f96e5u, 0xa44a9e08u, 0x0cd21d04u, 0xfeb0f6efu, 0xe1910a12u, 0x23d5e999u}},
+        {{0x76261b43u, 0xebde8470u, 0x967c84a5u, 0x2ed68098u, 0x3b4d3f69u, 0x711699fau, 0x952c0905u, 0x13c49044u},
+         {0x84282499u, 0x1f250413u, 0x20028021u, 0x3e2ddaeau, 0x2a48633du, 0x9fb1b228u, 0x59b1dd0bu, 0x16db366au}}
+    };
+    fq2 g[5];
+    for (int k = 0; k < 5; k++) { const auto& G = j == 1 ? G1[k] : G3[k]; g[k] = fq2{fq_from_raw(G[0]), fq_from_raw(G[1])}; }
+    return fq12{fq6{fq2_conj(a.c0.a0), f_mul(fq2_conj(a.c0.a1), g[1]), f_mul(fq2_conj(a.c0.a2), g[3])},
+                fq6{f_mul(fq2_conj(a.c1.a0), g[0]), f_mul(fq2_conj(a.c1.a1), g[2]), f_mul(fq2_conj(a.c1.a2), g[4])}};
+}
+ZKP_HD_NOINLINE inline fq12 fq12_pow_x(const fq12& a) {                // a^x, x = 4965661367192848881 (63 bits)
+    const uint64_t X = 4965661367192848881ull;
+    fq12 acc = a;
+    for (int i = 61; i >= 0; i--) {
+        acc = fq12_sq(acc);
+        if ((X >> i) & 1u) acc = fq12_mul(acc, a);
+    }
+    return acc;
+}
+// (inside the cyclotomic subgroup the inverse is the conjugate)
+ZKP_HD_NOINLINE inline fq12 final_exponentiation_chain(const fq12& f) {
+    const fq12 e1 = fq12_mul(fq12_conj(f), fq12_inv(f));               // f^(p^6 - 1)
+    const fq12 r = fq12_mul(fq12_frob_p2(e1), e1);                    // ^(p^2 + 1)
+    const fq12 y0 = fq12_conj(fq12_pow_x(r));                          // r^-x
+    const fq12 y1 = fq12_sq(y0);
+    const fq12 y3 = fq12_mul(fq12_sq(y1), y1);
+    const fq12 y4 = fq12_conj(fq12_pow_x(y3));
+    const fq12 y6 = fq12_pow_x(fq12_sq(y4));                           // (y5^-x)^-1
+    const fq12 y8 = fq12_mul(fq12_mul(y6, y4), fq12_conj(y3));
+    const fq12 y9 = fq12_mul(y8, y1);
+    const fq12 y11 = fq12_mul(fq12_mul(y8, y4), r);
+    const fq12 y13 = fq12_mul(fq12_frob_odd(y9, 1), y11);
+    const fq12 y14 = fq12_mul(fq12_frob_p2(y8), y13);
+    return fq12_mul(fq12_frob_odd(fq12_mul(fq12_conj(r), y9), 3), y14);
+}
 // the same power as one 2790-bit square-and-multiply (no inversion, no Frobenius): the test suite's cross-check
 ZKP_HD_NOINLINE inline fq12 final_exponentiation_naive(const fq12& f) {
     fq12 acc = fq12_one();

@@ -1,7 +1,8 @@
 // Groth16 verification of libzkp's equality / membership envelopes:
 // SnarkBackend::verify_equality_zk (/root/reference/src/backend/snark.rs:377-401) and verify_membership_zk (:455-495),
 // i.e. ark-groth16's  e(A, B) == e(alpha, beta) e(sum x_i IC_i, gamma) e(C, delta)  with the public-input order of
-// snark.rs:397-398,482-492.  One thread verifies one envelope (pairing: bn254_pairing.h); restated in
+// snark.rs:397-398,482-492.  Per envelope: one thread parses and accumulates the public inputs, three threads run the three
+// Miller loops, one thread multiplies and exponentiates (pairing: bn254_pairing.h); restated in
 // oracle/py/groth16.py: verify / verify_equality_with_commitment / verify_membership.
 #pragma once
 #include "bn254_pairing.h"
@@ -75,30 +76,39 @@ ZKP_HD inline g1_aff ld_ic(const G16Vk& vk, uint32_t i) {
     for (int k = 0; k < 10; k++) { p.x.v[k] = q[k]; p.y.v[k] = q[10 + k]; }
     return p;
 }
-// the pairing check for proof bytes (A || B || C) and the accumulated public-input point L (Jacobian)
-ZKP_HD_NOINLINE inline bool g16_check(const G16Vk& vk, const uint8_t proof[256], const g1_jac& L) {
+// The pairing check e(A, B) e(-L, gamma) e(-C, delta) e(-alpha, beta) == 1 as its three data-dependent Miller loops:
+// pair j contributes miller_loop(Q[j], P[j]) when bit j of `present` is set (a pair with a point at infinity contributes 1).
+struct G16Pairs { g1_aff P[3]; g2_aff Q[3]; uint32_t present; };
+// proof bytes (A || B || C) and the accumulated public-input point L (Jacobian); false: a point fails to parse
+ZKP_HD_NOINLINE inline bool g16_pairs(const G16Vk& vk, const uint8_t proof[256], const g1_jac& L, G16Pairs& o) {
     g1_aff A, C; g2_aff B;
     const int ra = g1_from_ark(A, proof), rb = g2_from_ark(B, proof + 64), rc = g1_from_ark(C, proof + 192);
+    o.present = 0;
     if (ra == 0 || rb == 0 || rc == 0) return false;
-    fq12 f = vk.ml_alpha_beta;
-    if (ra == 1 && rb == 1) f = fq12_mul(f, miller_loop(B, A));
+    if (ra == 1 && rb == 1) { o.P[0] = A; o.Q[0] = B; o.present |= 1u; }
     g1_aff La;
-    if (jac_to_aff(La, L)) f = fq12_mul(f, miller_loop(vk.gamma, aff_neg(La)));
-    if (rc == 1) f = fq12_mul(f, miller_loop(vk.delta, aff_neg(C)));
-    return fq12_is_one(final_exponentiation(f));
+    if (jac_to_aff(La, L)) { o.P[1] = aff_neg(La); o.Q[1] = vk.gamma; o.present |= 2u; }
+    if (rc == 1) { o.P[2] = aff_neg(C); o.Q[2] = vk.delta; o.present |= 4u; }
+    return true;
+}
+ZKP_HD inline fq12 g16_pair_miller(const G16Pairs& o, uint32_t j) { return (o.present >> j) & 1u ? miller_loop(o.Q[j], o.P[j]) : fq12_one(); }
+ZKP_HD_NOINLINE inline bool g16_finish(const G16Vk& vk, const fq12& f0, const fq12& f1, const fq12& f2) {
+    return fq12_is_one(final_exponentiation_chain(fq12_mul(fq12_mul(vk.ml_alpha_beta, f0), fq12_mul(f1, f2))));
 }
 // equality envelope (scheme 2, 298 bytes): public input = the embedded 32-byte commitment as an integer < r
-ZKP_HD_NOINLINE inline bool g16_verify_equality_envelope(const G16Vk& vk, const uint8_t* env, uint32_t len) {
+ZKP_HD_NOINLINE inline bool g16_equality_pairs(const G16Vk& vk, const uint8_t* env, uint32_t len, G16Pairs& o) {
+    o.present = 0;
     if (len != 298 || env[0] != 2 || env[1] != 2 || vk.n_ic != 2) return false;
     if (ld_u32_le(env + 2) != 256 || ld_u32_le(env + 6) != 32) return false;
     uint32_t c[8]; ld_le_words(c, env + 266);
     if (!fr_raw_lt_r(c)) return false;
     const g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), jac_mul_raw(jac_from_aff(ld_ic(vk, 1)), c));
-    return g16_check(vk, env + 10, L);
+    return g16_pairs(vk, env + 10, L, o);
 }
 // membership envelope (scheme 4): payload = u32 n || n x u64 set || 256-byte proof; public inputs =
 // commitment, 64 set slots (zero padded), 64 is_real flags (snark.rs:482-492)
-ZKP_HD_NOINLINE inline bool g16_verify_membership_envelope(const G16Vk& vk, const uint8_t* env, uint32_t len) {
+ZKP_HD_NOINLINE inline bool g16_membership_pairs(const G16Vk& vk, const uint8_t* env, uint32_t len, G16Pairs& o) {
+    o.present = 0;
     if (len < 10 + 4 + 256 + 32 || env[0] != 2 || env[1] != 4 || vk.n_ic != 2 + 2 * G16_MAX_SET) return false;
     const uint32_t plen = ld_u32_le(env + 2), clen = ld_u32_le(env + 6);
     if (clen != 32 || (uint64_t)10 + plen + clen != len || plen < 4 + 256) return false;
@@ -112,7 +122,13 @@ ZKP_HD_NOINLINE inline bool g16_verify_membership_envelope(const G16Vk& vk, cons
         if (v) L = jac_add(L, g1_mul_u64(ld_ic(vk, 2 + i), v));
         L = jac_madd(L, ld_ic(vk, 2 + G16_MAX_SET + i));            // is_real = 1
     }
-    return g16_check(vk, env + 14 + 8 * n, L);
+    return g16_pairs(vk, env + 14 + 8 * n, L, o);
+}
+// one envelope start to finish in one thread (what the three GPU kernels compute between them; used by the host emulation)
+ZKP_HD inline bool g16_verify_envelope(int kind, const G16Vk& vk, const uint8_t* env, uint32_t len) {
+    G16Pairs o;
+    if (!(kind == G16_EQUALITY ? g16_equality_pairs(vk, env, len, o) : g16_membership_pairs(vk, env, len, o))) return false;
+    return g16_finish(vk, g16_pair_miller(o, 0), g16_pair_miller(o, 1), g16_pair_miller(o, 2));
 }
 
 }  // namespace zkp

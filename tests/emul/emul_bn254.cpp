@@ -99,6 +99,8 @@ void emul_f12_mul(const uint32_t a[96], const uint32_t b[96], int square, uint32
 // prod_i ate(Q_i, P_i) == 1 ?  points as raw affine coordinates (16 / 32 words each)
 // final exponentiation two ways (easy/hard split vs one 2790-bit power) and the Fq12 inverse, in the oracle's basis
 void emul_f12_final_exp(const uint32_t a[96], int naive, uint32_t out[96]) { f12_to_poly(out, naive ? final_exponentiation_naive(f12_from_poly(a)) : final_exponentiation(f12_from_poly(a))); }
+void emul_f12_final_exp_chain(const uint32_t a[96], uint32_t out[96]) { f12_to_poly(out, final_exponentiation_chain(f12_from_poly(a))); }
+void emul_f12_frob(const uint32_t a[96], int j, uint32_t out[96]) { f12_to_poly(out, j == 2 ? fq12_frob_p2(f12_from_poly(a)) : fq12_frob_odd(f12_from_poly(a), j)); }
 void emul_f12_inv(const uint32_t a[96], uint32_t out[96]) { f12_to_poly(out, fq12_inv(f12_from_poly(a))); }
 int emul_pairing_product_is_one(int n, const uint32_t* g1s, const uint32_t* g2s) {
     fq12 f = fq12_one();

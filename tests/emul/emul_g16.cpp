@@ -62,6 +62,6 @@ int emul_g16_verify(int kind, const uint8_t* env, uint32_t len, const uint32_t* 
     for (uint32_t i = 0; i < n_ic; i++) { const g1_aff p = g1(ic + 16 * i); for (int k = 0; k < 10; k++) { icm[20 * i + k] = p.x.v[k]; icm[20 * i + 10 + k] = p.y.v[k]; } }
     G16Vk vk; vk.gamma = g2(gamma); vk.delta = g2(delta); vk.n_ic = n_ic; vk.ic = icm.data();
     vk.ml_alpha_beta = miller_loop(g2(beta), aff_neg(g1(alpha)));
-    return (kind == 0 ? g16_verify_equality_envelope(vk, env, len) : g16_verify_membership_envelope(vk, env, len)) ? 1 : 0;
+    return g16_verify_envelope(kind, vk, env, len) ? 1 : 0;
 }
 }

@@ -181,6 +181,12 @@ def test_tower_and_pairing(libs):
         lib.emul_f12_final_exp(W12(x), 1, out2)
         assert I12(out) == I12(out2)
     assert I12(out) == b.final_exponentiate(x)
+    X = 4965661367192848881                                     # addition-chain variant: the same power raised to m = 2x(6x^2 + 3x + 1)
+    lib.emul_f12_final_exp_chain(W12(x), out2)
+    assert I12(out2) == b.f12_pow(I12(out), 2 * X * (6 * X * X + 3 * X + 1))
+    for j in (1, 2, 3):
+        lib.emul_f12_frob(W12(x), j, out2)
+        assert I12(out2) == b.f12_pow(x, b.P ** j)
     g1w = lambda pt: [(pt[0] >> (32 * i)) & 0xFFFFFFFF for i in range(8)] + [(pt[1] >> (32 * i)) & 0xFFFFFFFF for i in range(8)]  # noqa: E731
 
     def g2w(pt):
