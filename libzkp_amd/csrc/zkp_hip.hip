@@ -151,16 +151,56 @@ int fail(int code, const std::string& msg) { t_err = msg; return code; }
         if (e_ != hipSuccess) return fail(ZKP_HIP_E_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-// Per-call device buffers: released when the call returns, on every path (HIP_TRY returns early on errors).
+// Per-call device buffers (staging of host inputs / outputs): handed back when the call returns, on every path (HIP_TRY
+// returns early on errors).  Blocks are kept in a small pool instead of going through hipMalloc / hipFree on every call
+// (hipFree synchronises the device; a one-proof call spent a third of its time there): a block is reused for requests
+// between half its size and its size, and the pool is emptied when it holds more than DEV_POOL_LIMIT bytes of idle blocks.
+struct DevPool {
+    struct Block { void* p; size_t bytes; bool busy; };
+    std::vector<Block> blocks;
+    std::mutex mu;
+    static constexpr size_t DEV_POOL_LIMIT = (size_t)1 << 30;
+    const bool bypass = getenv("ZKP_HIP_NO_POOL") != nullptr;        // debugging knob: plain hipMalloc / hipFree per call
+    hipError_t take(void** out, size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!bypass) for (auto& b : blocks) if (!b.busy && b.bytes >= bytes && b.bytes / 2 <= bytes) { b.busy = true; *out = b.p; return hipSuccess; }
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, bytes);
+        if (e != hipSuccess) {                       // out of memory: drop the idle blocks and try once more
+            trim_locked(0);
+            (void)hipGetLastError();
+            e = hipMalloc(&q, bytes);
+            if (e != hipSuccess) { *out = nullptr; return e; }
+        }
+        blocks.push_back({q, bytes, true});
+        *out = q;
+        return hipSuccess;
+    }
+    void give(void* p) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& b : blocks) if (b.p == p) b.busy = false;
+        trim_locked(bypass ? 0 : DEV_POOL_LIMIT);
+    }
+    void trim_locked(size_t keep) {
+        size_t idle = 0; for (auto& b : blocks) if (!b.busy) idle += b.bytes;
+        if (idle <= keep) return;
+        std::vector<Block> rest;
+        for (auto& b : blocks) { if (b.busy) rest.push_back(b); else (void)hipFree(b.p); }
+        blocks.swap(rest);
+    }
+    void release_all() { std::lock_guard<std::mutex> lk(mu); trim_locked(0); }
+};
+DevPool g_pool;
+void dev_scope_quiesce();       // waits for the library's own stream: a block must be idle before it goes back to the pool
 struct DevScope {
     std::vector<void*> owned;
     DevScope() = default;
     DevScope(const DevScope&) = delete;
     DevScope& operator=(const DevScope&) = delete;
-    ~DevScope() { for (void* q : owned) (void)hipFree(q); }
+    ~DevScope() { if (!owned.empty()) dev_scope_quiesce(); for (void* q : owned) g_pool.give(q); }
     template <class T> hipError_t alloc(T** out, size_t bytes) {
         void* q = nullptr;
-        const hipError_t e = hipMalloc(&q, bytes ? bytes : 1);
+        const hipError_t e = g_pool.take(&q, bytes ? bytes : 1);
         if (e == hipSuccess) owned.push_back(q);
         *out = static_cast<T*>(q);
         return e;
@@ -212,6 +252,7 @@ struct Ctx {
 };
 Ctx g;
 std::mutex g_mu;
+void dev_scope_quiesce() { if (g.stream) (void)hipStreamSynchronize(g.stream); }
 uint32_t g_budget_request = 0;     // 0 = choose per launch
 double g_fill = 1.0;               // benchmarking knob: scales the resident-workgroup count the Bulletproofs MSM chunking aims at
 uint32_t g_subbatches = 1;         // >1: independent slices on separate streams (measured slower on MI355X: see DESIGN.md)
@@ -605,6 +646,7 @@ void zkp_hip_shutdown(void) {
     (void)hipDeviceSynchronize();
     g16_release_all();
     bpv_release_all();
+    g_pool.release_all();
     if (g_stark_const) { (void)hipFree(g_stark_const); g_stark_const = nullptr; }
     for (auto& sb : g.sub) {
         (void)hipFree(sb.ws); (void)hipStreamDestroy(sb.stream); (void)hipStreamDestroy(sb.side);
