@@ -33,13 +33,15 @@ enum {
 /* Library-level return values: 0 = every item succeeded, 1 = at least one item has status != 0
  * (outputs of the other items are still valid), < 0 = the call itself failed (see zkp_hip_last_error). */
 #define ZKP_HIP_E_RUNTIME (-1)       /* HIP runtime error / no device / out of memory */
-#define ZKP_HIP_E_UNSUPPORTED (-2)   /* e.g. n_bits != 64 */
+#define ZKP_HIP_E_UNSUPPORTED (-2)   /* e.g. n_bits other than 8, 16, 32, 64 */
 #define ZKP_HIP_E_ARGUMENT (-3)
 
 /* One-time setup on `device`: derives the 130 Bulletproofs generators (PedersenGens::default,
  * BulletproofGens::new party 0; replaces bp_gens_pair_bits, bulletproofs.rs:61-80), builds the
  * fixed-base window tables and uploads them.  Idempotent.  Called implicitly by the prove calls. */
 int zkp_hip_init(int device);
+/* Releases every device resource (tables, loaded keys, workspaces, pooled staging buffers, streams); a later call
+ * initialises again (keys must be loaded again). */
 void zkp_hip_shutdown(void);
 /* Thread-local description of the last failure of a call made on this thread. */
 const char* zkp_hip_last_error(void);

@@ -201,6 +201,7 @@ def prove_consistency(data):
 MAX_SET_SIZE = 64
 _key_dir_override = None
 _keys_loaded = {}
+_reinstall = {}            # kind -> key bytes to load again on first use after shutdown()
 _key_blobs = {}            # kind -> proving-key bytes of the loaded key (multi-GPU: rank 0's key is broadcast, sharding.py)
 _KEY_PREFIX = {0: "equality_mimc", 1: "membership_mimc"}          # snark.rs:306,327
 _snark_lock = threading.Lock()
@@ -234,7 +235,13 @@ def _ensure_key(kind):
         d = _key_dir_override or os.environ.get("LIBZKP_SNARK_KEY_DIR")
         L = _native.lib()
         path = os.path.join(d, _KEY_PREFIX[kind] + "_pk.bin") if d else None
-        if path and os.path.exists(path):
+        if kind in _reinstall:                                      # after shutdown(): the process keeps ONE setup per circuit
+            blob = _reinstall.pop(kind)
+            if L.zkp_hip_groth16_load_key(kind, blob, len(blob)) != 0:
+                raise ZkpBackendError("Configuration error: %s" % _native.last_error())
+            _key_blobs[kind] = blob
+            path = path or "<reinstalled>"
+        elif path and os.path.exists(path):
             blob = open(path, "rb").read()
             if L.zkp_hip_groth16_load_key(kind, blob, len(blob)) != 0:
                 raise ZkpBackendError("Configuration error: %s" % _native.last_error())
@@ -256,6 +263,15 @@ def _ensure_key(kind):
             _key_blobs[kind] = pk.raw[: pk_len.value]
             path = path or "<generated in memory>"
         _keys_loaded[kind] = path
+
+
+def shutdown():
+    """Release every device resource of the library (tables, keys, workspaces, streams).  The next call initialises again;
+    the Groth16 keys of this process are kept on the host and reinstalled on first use, so proofs made before still verify."""
+    with _snark_lock:
+        _native.lib().zkp_hip_shutdown()
+        _reinstall.update({k: _key_blobs[k] for k in _keys_loaded if k in _key_blobs})
+        _keys_loaded.clear()
 
 
 def export_proving_key(kind):
