@@ -93,6 +93,66 @@ __device__ __forceinline__ FeB mulB(const FeB& f, const FeB& g) {
     return o;
 }
 
+// B1: the product form libzkp_amd/csrc/fe25519.h uses -- each column's v_mad_u64_u32 chain starts from the previous column's carry
+__device__ __forceinline__ FeB mulB1(const FeB& f, const FeB& g) {
+    uint32_t g19[10], f2[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) g19[i] = 19u * g.v[i];
+#pragma unroll
+    for (int i = 1; i < 10; i += 2) f2[i] = 2u * f.v[i];
+    FeB o;
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        uint64_t acc = c;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            int j = k - i;
+            const bool wrap = j < 0;
+            if (wrap) j += 10;
+            const uint32_t fi = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
+            acc += (uint64_t)fi * (wrap ? g19[j] : g.v[j]);
+        }
+        const int bits = (k & 1) ? 25 : 26;
+        o.v[k] = (uint32_t)acc & ((1u << bits) - 1);
+        c = acc >> bits;
+    }
+    const uint64_t t = (uint64_t)o.v[0] + c * 19;
+    o.v[0] = (uint32_t)t & 0x3ffffffu;
+    o.v[1] += (uint32_t)(t >> 26);
+    return o;
+}
+// B2: B1 with the 64-bit carry shift written as two 32-bit operations (funnel shift + shift)
+__device__ __forceinline__ FeB mulB2(const FeB& f, const FeB& g) {
+    uint32_t g19[10], f2[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) g19[i] = 19u * g.v[i];
+#pragma unroll
+    for (int i = 1; i < 10; i += 2) f2[i] = 2u * f.v[i];
+    FeB o;
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        uint64_t acc = c;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            int j = k - i;
+            const bool wrap = j < 0;
+            if (wrap) j += 10;
+            const uint32_t fi = ((i & 1) && (j & 1)) ? f2[i] : f.v[i];
+            acc += (uint64_t)fi * (wrap ? g19[j] : g.v[j]);
+        }
+        const int bits = (k & 1) ? 25 : 26;
+        const uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+        o.v[k] = lo & ((1u << bits) - 1);
+        c = ((uint64_t)(hi >> bits) << 32) | __builtin_amdgcn_alignbit(hi, lo, bits);
+    }
+    const uint64_t t = (uint64_t)o.v[0] + c * 19;
+    o.v[0] = (uint32_t)t & 0x3ffffffu;
+    o.v[1] += (uint32_t)(t >> 26);
+    return o;
+}
+
 // ---------------------------------------------------------------- C: 12 doubles, position-scaled
 // limb i holds a_i * 2^{p_i}, p_i = ceil(64*i/3): 0,22,43,64,86,107,128,150,171,192,214,235 ; p_12 = 256
 struct FeC { double v[12]; };
@@ -205,6 +265,8 @@ int main(int argc, char** argv) {
     }
     run<FeA, mulA>("A_8x32", ia, blocks, iters, printA);
     run<FeB, mulB>("B_10x25.5", ib, blocks, iters, printB);
+    run<FeB, mulB1>("B1_10x25.5_seeded_carry", ib, blocks, iters, printB);
+    run<FeB, mulB2>("B2_10x25.5_alignbit_carry", ib, blocks, iters, printB);
     run<FeC, mulC>("C_12xf64", ic, blocks, iters, printC);
     return 0;
 }
