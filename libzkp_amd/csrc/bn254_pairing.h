@@ -50,25 +50,39 @@ ZKP_HD_NOINLINE inline fq12 fq12_sq(const fq12& a) {      // (c0 + c1 w)^2 = (c0
 ZKP_HD inline bool fq12_is_one(const fq12& a) {
     return fq2_eq(a.c0.a0, fq2_one()) && f_is_zero(a.c0.a1) && f_is_zero(a.c0.a2) && f_is_zero(a.c1.a0) && f_is_zero(a.c1.a1) && f_is_zero(a.c1.a2);
 }
-// the line l = A + (B + C v) w  (A, B, C in Fq2) as an Fq12 element
+// the line l = A + (B + C v) w  (A, B, C in Fq2): three of the six Fq2 coefficients of an Fq12 element
+struct fq12_line { fq2 A, B, C; };
 ZKP_HD inline fq12 fq12_from_line(const fq2& A, const fq2& B, const fq2& C) { return fq12{fq6{A, fq2_zero(), fq2_zero()}, fq6{B, C, fq2_zero()}}; }
+ZKP_HD inline fq6 fq6_mul_fq2(const fq6& a, const fq2& k) { return fq6{f_mul(a.a0, k), f_mul(a.a1, k), f_mul(a.a2, k)}; }
+// a * (b0 + b1 v): five Fq2 products
+ZKP_HD inline fq6 fq6_mul_sparse2(const fq6& a, const fq2& b0, const fq2& b1) {
+    const fq2 v0 = f_mul(a.a0, b0), v1 = f_mul(a.a1, b1);
+    const fq2 mid = f_sub(f_sub(f_mul(f_add(a.a0, a.a1), f_add(b0, b1)), v0), v1);      // a0 b1 + a1 b0
+    return fq6{f_add(v0, fq2_mul_xi(f_mul(a.a2, b1))), mid, f_add(v1, f_mul(a.a2, b0))};
+}
+// f * l for a line: 13 Fq2 products instead of the 18 of a general product
+ZKP_HD_NOINLINE inline fq12 fq12_mul_line(const fq12& f, const fq12_line& l) {
+    const fq6 t0 = fq6_mul_fq2(f.c0, l.A), t1 = fq6_mul_sparse2(f.c1, l.B, l.C);
+    const fq6 m = fq6_mul_sparse2(fq6_add(f.c0, f.c1), f_add(l.A, l.B), l.C);
+    return fq12{fq6_add(t0, fq6_mul_v(t1)), fq6_sub(fq6_sub(m, t0), t1)};
+}
 
 // tangent at T (Jacobian over Fq2, twisted curve) evaluated at P = (xp, yp) in G1, scaled by subfield factors:
 //   2 Y Z^3 yp  -  3 X^2 Z^2 xp w  +  (3 X^3 - 2 Y^2) w^3        (w^3 = v w)
-ZKP_HD_NOINLINE inline fq12 line_double(const g2_jac& T, const fq& xp, const fq& yp) {
+ZKP_HD_NOINLINE inline fq12_line line_double(const g2_jac& T, const fq& xp, const fq& yp) {
     const fq2 XX = f_sq(T.X), YY = f_sq(T.Y), ZZ = f_sq(T.Z);
     const fq2 A = fq2_mul_fq(f_dbl(f_mul(f_mul(T.Y, T.Z), ZZ)), yp);
     const fq2 x3 = f_add(f_dbl(XX), XX);                                  // 3 X^2
     const fq2 B = f_neg(fq2_mul_fq(f_mul(x3, ZZ), xp));
     const fq2 C = f_sub(f_mul(x3, T.X), f_dbl(YY));
-    return fq12_from_line(A, B, C);
+    return fq12_line{A, B, C};
 }
 // chord through T (Jacobian) and Q (affine):  D yp - N xp w + (N x2 - D y2) w^3,  N = y2 Z^3 - Y,  D = (x2 Z^2 - X) Z
-ZKP_HD_NOINLINE inline fq12 line_add(const g2_jac& T, const g2_aff& Q, const fq& xp, const fq& yp) {
+ZKP_HD_NOINLINE inline fq12_line line_add(const g2_jac& T, const g2_aff& Q, const fq& xp, const fq& yp) {
     const fq2 ZZ = f_sq(T.Z);
     const fq2 N = f_sub(f_mul(f_mul(Q.y, T.Z), ZZ), T.Y);
     const fq2 D = f_mul(f_sub(f_mul(Q.x, ZZ), T.X), T.Z);
-    return fq12_from_line(fq2_mul_fq(D, yp), f_neg(fq2_mul_fq(N, xp)), f_sub(f_mul(N, Q.x), f_mul(D, Q.y)));
+    return fq12_line{fq2_mul_fq(D, yp), f_neg(fq2_mul_fq(N, xp)), f_sub(f_mul(N, Q.x), f_mul(D, Q.y))};
 }
 // f_{t-1,Q}(P), t - 1 = 6 x^2 = 0x6f4d8248eeb859fbf83e9682e87cfd46 (127 bits)
 ZKP_HD_NOINLINE inline fq12 miller_loop(const g2_aff& Q, const g1_aff& P) {
@@ -76,10 +90,10 @@ ZKP_HD_NOINLINE inline fq12 miller_loop(const g2_aff& Q, const g1_aff& P) {
     fq12 f = fq12_one();
     g2_jac T = jac_from_aff(Q);
     for (int i = 125; i >= 0; i--) {
-        f = fq12_mul(fq12_sq(f), line_double(T, P.x, P.y));
+        f = fq12_mul_line(fq12_sq(f), line_double(T, P.x, P.y));
         T = jac_dbl(T);
         if ((T1[i >> 5] >> (i & 31)) & 1u) {
-            f = fq12_mul(f, line_add(T, Q, P.x, P.y));
+            f = fq12_mul_line(f, line_add(T, Q, P.x, P.y));
             T = jac_madd(T, Q);
         }
     }
@@ -103,7 +117,6 @@ ZKP_HD constexpr uint32_t final_exp_word(int i) {
 }
 // ---- final exponentiation f^((p^12 - 1)/r) = ((f^(p^6 - 1))^(p^2 + 1))^((p^4 - p^2 + 1)/r)
 ZKP_HD inline fq6 fq6_neg(const fq6& a) { return fq6{f_neg(a.a0), f_neg(a.a1), f_neg(a.a2)}; }
-ZKP_HD inline fq6 fq6_mul_fq2(const fq6& a, const fq2& k) { return fq6{f_mul(a.a0, k), f_mul(a.a1, k), f_mul(a.a2, k)}; }
 ZKP_HD_NOINLINE inline fq6 fq6_inv(const fq6& a) {
     const fq2 A = f_sub(f_sq(a.a0), fq2_mul_xi(f_mul(a.a1, a.a2)));
     const fq2 B = f_sub(fq2_mul_xi(f_sq(a.a2)), f_mul(a.a0, a.a1));
@@ -182,11 +195,33 @@ ZKP_HD_NOINLINE inline fq12 fq12_frob_odd(const fq12& a, int j) {      // j = 1 
     return fq12{fq6{fq2_conj(a.c0.a0), f_mul(fq2_conj(a.c0.a1), g[1]), f_mul(fq2_conj(a.c0.a2), g[3])},
                 fq6{f_mul(fq2_conj(a.c1.a0), g[0]), f_mul(fq2_conj(a.c1.a1), g[2]), f_mul(fq2_conj(a.c1.a2), g[4])}};
 }
-ZKP_HD_NOINLINE inline fq12 fq12_pow_x(const fq12& a) {                // a^x, x = 4965661367192848881 (63 bits)
+// Squaring inside the cyclotomic subgroup (Granger-Scott): with s = w^3, t = w the element is A + B t + C t^2 over
+// Fq4 = Fq2[s]/(s^2 - xi), A = a0 + b1 s, B = b0 + a2 s, C = a1 + b2 s (a_i, b_i the Fq2 coefficients of c0, c1), and
+// f^2 = (3A^2 - 2 conj A) + (3 s C^2 + 2 conj B) t + (3B^2 - 2 conj C) t^2: three Fq4 squarings = 9 Fq2 squarings, half the
+// work of the general fq12_sq.  Only valid after the easy part of the final exponentiation.
+ZKP_HD inline void fq4_sq(fq2& re, fq2& im, const fq2& x, const fq2& y) {       // (x + y s)^2 = (x^2 + xi y^2) + 2xy s
+    const fq2 xx = f_sq(x), yy = f_sq(y);
+    re = f_add(xx, fq2_mul_xi(yy));
+    im = f_sub(f_sub(f_sq(f_add(x, y)), xx), yy);
+}
+ZKP_HD_NOINLINE inline fq12 fq12_cyclo_sq(const fq12& f) {
+    fq2 t0, t1, t2, t3, t4, t5;
+    fq4_sq(t0, t1, f.c0.a0, f.c1.a1);
+    fq4_sq(t2, t3, f.c1.a0, f.c0.a2);
+    fq4_sq(t4, t5, f.c0.a1, f.c1.a2);
+    auto three_minus_two = [](const fq2& t, const fq2& z) { return f_sub(f_add(f_dbl(t), t), f_dbl(z)); };   // 3t - 2z
+    auto three_plus_two = [](const fq2& t, const fq2& z) { return f_add(f_add(f_dbl(t), t), f_dbl(z)); };    // 3t + 2z
+    fq12 r;
+    r.c0.a0 = three_minus_two(t0, f.c0.a0); r.c1.a1 = three_plus_two(t1, f.c1.a1);
+    r.c1.a0 = three_plus_two(fq2_mul_xi(t5), f.c1.a0); r.c0.a2 = three_minus_two(t4, f.c0.a2);
+    r.c0.a1 = three_minus_two(t2, f.c0.a1); r.c1.a2 = three_plus_two(t3, f.c1.a2);
+    return r;
+}
+ZKP_HD_NOINLINE inline fq12 fq12_pow_x(const fq12& a) {                // a^x, x = 4965661367192848881 (63 bits); a cyclotomic
     const uint64_t X = 4965661367192848881ull;
     fq12 acc = a;
     for (int i = 61; i >= 0; i--) {
-        acc = fq12_sq(acc);
+        acc = fq12_cyclo_sq(acc);
         if ((X >> i) & 1u) acc = fq12_mul(acc, a);
     }
     return acc;
@@ -196,10 +231,10 @@ ZKP_HD_NOINLINE inline fq12 final_exponentiation_chain(const fq12& f) {
     const fq12 e1 = fq12_mul(fq12_conj(f), fq12_inv(f));               // f^(p^6 - 1)
     const fq12 r = fq12_mul(fq12_frob_p2(e1), e1);                    // ^(p^2 + 1)
     const fq12 y0 = fq12_conj(fq12_pow_x(r));                          // r^-x
-    const fq12 y1 = fq12_sq(y0);
-    const fq12 y3 = fq12_mul(fq12_sq(y1), y1);
+    const fq12 y1 = fq12_cyclo_sq(y0);
+    const fq12 y3 = fq12_mul(fq12_cyclo_sq(y1), y1);
     const fq12 y4 = fq12_conj(fq12_pow_x(y3));
-    const fq12 y6 = fq12_pow_x(fq12_sq(y4));                           // (y5^-x)^-1
+    const fq12 y6 = fq12_pow_x(fq12_cyclo_sq(y4));                     // (y5^-x)^-1
     const fq12 y8 = fq12_mul(fq12_mul(y6, y4), fq12_conj(y3));
     const fq12 y9 = fq12_mul(y8, y1);
     const fq12 y11 = fq12_mul(fq12_mul(y8, y4), r);

@@ -44,6 +44,7 @@ ZKP_HD_NOINLINE inline int g1_from_ark(g1_aff& out, const uint8_t b[64]) {
     if (((flags & 0x80u) != 0) != fq_raw_gt_half(yw)) return 0;
     return 1;
 }
+// (the subgroup check of a finite point is g2_in_subgroup: the most expensive part, which the GPU path runs on a lane of its own)
 ZKP_HD_NOINLINE inline int g2_from_ark(g2_aff& out, const uint8_t b[128]) {
     const uint32_t flags = b[127] & 0xC0u;
     if (flags & 0x40u) return 2;
@@ -57,10 +58,12 @@ ZKP_HD_NOINLINE inline int g2_from_ark(g2_aff& out, const uint8_t b[128]) {
     uint32_t nz = 0; for (int i = 0; i < 8; i++) nz |= w[3][i];
     const bool larger = nz ? fq_raw_gt_half(w[3]) : fq_raw_gt_half(w[2]);
     if (((flags & 0x80u) != 0) != larger) return 0;
-    // subgroup check: G2 has a cofactor, r * Q must be the identity
-    uint32_t rw[8]; for (int i = 0; i < 8; i++) rw[i] = FrParams::mod(i);
-    if (!jac_is_inf(jac_mul_raw(jac_from_aff(out), rw))) return 0;
     return 1;
+}
+// G2 has a cofactor: r * Q must be the identity
+ZKP_HD_NOINLINE inline bool g2_in_subgroup(const g2_aff& q) {
+    uint32_t rw[8]; for (int i = 0; i < 8; i++) rw[i] = FrParams::mod(i);
+    return jac_is_inf(jac_mul_raw(jac_from_aff(q), rw));
 }
 // k * P for a 64-bit scalar (set elements)
 ZKP_HD inline g1_jac g1_mul_u64(const g1_aff& p, uint64_t k) {
@@ -77,7 +80,8 @@ ZKP_HD inline g1_aff ld_ic(const G16Vk& vk, uint32_t i) {
     return p;
 }
 // The pairing check e(A, B) e(-L, gamma) e(-C, delta) e(-alpha, beta) == 1 as its three data-dependent Miller loops:
-// pair j contributes miller_loop(Q[j], P[j]) when bit j of `present` is set (a pair with a point at infinity contributes 1).
+// pair j contributes miller_loop(Q[j], P[j]) when bit j of `present` is set (a pair with a point at infinity contributes 1);
+// bit 3: Q[0] holds a finite B whose subgroup membership is still to be checked (g16_b_in_subgroup).
 struct G16Pairs { g1_aff P[3]; g2_aff Q[3]; uint32_t present; };
 // proof bytes (A || B || C) and the accumulated public-input point L (Jacobian); false: a point fails to parse
 ZKP_HD_NOINLINE inline bool g16_pairs(const G16Vk& vk, const uint8_t proof[256], const g1_jac& L, G16Pairs& o) {
@@ -85,12 +89,14 @@ ZKP_HD_NOINLINE inline bool g16_pairs(const G16Vk& vk, const uint8_t proof[256],
     const int ra = g1_from_ark(A, proof), rb = g2_from_ark(B, proof + 64), rc = g1_from_ark(C, proof + 192);
     o.present = 0;
     if (ra == 0 || rb == 0 || rc == 0) return false;
-    if (ra == 1 && rb == 1) { o.P[0] = A; o.Q[0] = B; o.present |= 1u; }
+    if (rb == 1) { o.Q[0] = B; o.present |= 8u; }
+    if (ra == 1 && rb == 1) { o.P[0] = A; o.present |= 1u; }
     g1_aff La;
     if (jac_to_aff(La, L)) { o.P[1] = aff_neg(La); o.Q[1] = vk.gamma; o.present |= 2u; }
     if (rc == 1) { o.P[2] = aff_neg(C); o.Q[2] = vk.delta; o.present |= 4u; }
     return true;
 }
+ZKP_HD inline bool g16_b_in_subgroup(const G16Pairs& o) { return (o.present & 8u) == 0 || g2_in_subgroup(o.Q[0]); }
 ZKP_HD inline fq12 g16_pair_miller(const G16Pairs& o, uint32_t j) { return (o.present >> j) & 1u ? miller_loop(o.Q[j], o.P[j]) : fq12_one(); }
 ZKP_HD_NOINLINE inline bool g16_finish(const G16Vk& vk, const fq12& f0, const fq12& f1, const fq12& f2) {
     return fq12_is_one(final_exponentiation_chain(fq12_mul(fq12_mul(vk.ml_alpha_beta, f0), fq12_mul(f1, f2))));
@@ -128,6 +134,7 @@ ZKP_HD_NOINLINE inline bool g16_membership_pairs(const G16Vk& vk, const uint8_t*
 ZKP_HD inline bool g16_verify_envelope(int kind, const G16Vk& vk, const uint8_t* env, uint32_t len) {
     G16Pairs o;
     if (!(kind == G16_EQUALITY ? g16_equality_pairs(vk, env, len, o) : g16_membership_pairs(vk, env, len, o))) return false;
+    if (!g16_b_in_subgroup(o)) return false;
     return g16_finish(vk, g16_pair_miller(o, 0), g16_pair_miller(o, 1), g16_pair_miller(o, 2));
 }
 

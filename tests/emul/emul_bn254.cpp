@@ -101,6 +101,19 @@ void emul_f12_mul(const uint32_t a[96], const uint32_t b[96], int square, uint32
 void emul_f12_final_exp(const uint32_t a[96], int naive, uint32_t out[96]) { f12_to_poly(out, naive ? final_exponentiation_naive(f12_from_poly(a)) : final_exponentiation(f12_from_poly(a))); }
 void emul_f12_final_exp_chain(const uint32_t a[96], uint32_t out[96]) { f12_to_poly(out, final_exponentiation_chain(f12_from_poly(a))); }
 void emul_f12_frob(const uint32_t a[96], int j, uint32_t out[96]) { f12_to_poly(out, j == 2 ? fq12_frob_p2(f12_from_poly(a)) : fq12_frob_odd(f12_from_poly(a), j)); }
+// squaring of the easy part's output (an element of the cyclotomic subgroup): general (0) or Granger-Scott (1)
+void emul_f12_cyclo_sq(const uint32_t a[96], int gs, uint32_t out[96]) {
+    const fq12 f = f12_from_poly(a);
+    const fq12 e1 = fq12_mul(fq12_conj(f), fq12_inv(f)), r = fq12_mul(fq12_frob_p2(e1), e1);
+    f12_to_poly(out, gs ? fq12_cyclo_sq(r) : fq12_sq(r));
+}
+// f * line(A, B, C) by the sparse product (1) or the general one on the embedded line (0); abc = 3 x (c0, c1) raw words
+void emul_f12_mul_line(const uint32_t a[96], const uint32_t abc[48], int sparse, uint32_t out[96]) {
+    auto f2 = [&](int k) { return fq2{fq_from_raw(abc + 16 * k), fq_from_raw(abc + 16 * k + 8)}; };
+    const fq12 f = f12_from_poly(a);
+    const fq12_line l{f2(0), f2(1), f2(2)};
+    f12_to_poly(out, sparse ? fq12_mul_line(f, l) : fq12_mul(f, fq12_from_line(l.A, l.B, l.C)));
+}
 void emul_f12_inv(const uint32_t a[96], uint32_t out[96]) { f12_to_poly(out, fq12_inv(f12_from_poly(a))); }
 int emul_pairing_product_is_one(int n, const uint32_t* g1s, const uint32_t* g2s) {
     fq12 f = fq12_one();

@@ -184,6 +184,13 @@ def test_tower_and_pairing(libs):
     X = 4965661367192848881                                     # addition-chain variant: the same power raised to m = 2x(6x^2 + 3x + 1)
     lib.emul_f12_final_exp_chain(W12(x), out2)
     assert I12(out2) == b.f12_pow(I12(out), 2 * X * (6 * X * X + 3 * X + 1))
+    lib.emul_f12_cyclo_sq(W12(x), 0, out)                       # Granger-Scott squaring == general squaring inside the cyclotomic subgroup
+    lib.emul_f12_cyclo_sq(W12(x), 1, out2)
+    assert I12(out) == I12(out2)
+    abc = (ctypes.c_uint32 * 48)(*[(v >> (32 * i)) & 0xFFFFFFFF for v in [rnd.randrange(b.P) for _ in range(6)] for i in range(8)])
+    lib.emul_f12_mul_line(W12(x), abc, 0, out)                  # sparse line product == general product
+    lib.emul_f12_mul_line(W12(x), abc, 1, out2)
+    assert I12(out) == I12(out2)
     for j in (1, 2, 3):
         lib.emul_f12_frob(W12(x), j, out2)
         assert I12(out2) == b.f12_pow(x, b.P ** j)
