@@ -30,6 +30,27 @@ def _check_u64(name, x):
     return int(x)
 
 
+def _u64_array(name, xs):
+    """u64 column of a batch.  Unsigned numpy arrays are taken as they are; anything else is checked element by element."""
+    if isinstance(xs, np.ndarray) and xs.dtype.kind == "u" and xs.ndim == 1:
+        return np.ascontiguousarray(xs, dtype=np.uint64)
+    return np.array([_check_u64(name, x) for x in xs], dtype=np.uint64)
+
+
+def _rows(blobs, cap=4096):
+    """Byte strings of a batch as rows of one buffer (stride = the longest, at most `cap`: longer ones are rejected by the
+    library through their recorded length).  Equal lengths -- the usual case -- are packed without a Python loop."""
+    n = len(blobs)
+    lens = np.fromiter((len(b) for b in blobs), dtype=np.uint32, count=n)
+    stride = int(min(cap, max(16, int(lens.max()))))
+    if int(lens.min()) == int(lens.max()) == stride:
+        return np.frombuffer(b"".join(blobs), dtype=np.uint8).reshape(n, stride).copy(), lens, stride
+    buf = np.zeros((n, stride), dtype=np.uint8)
+    for i, b in enumerate(blobs):
+        buf[i, : min(len(b), stride)] = np.frombuffer(b[:stride], dtype=np.uint8)
+    return buf, lens, stride
+
+
 def validate_range_params(value, mn, mx):
     """validation.rs:5-18."""
     if mn > mx:
@@ -65,16 +86,16 @@ def prove_range_batch(values, mins, maxs, seeds=None, device=None, n_bits=64):
     """
     n = len(values)
     n_bits = _check_bits(n_bits, "min range")
-    v = np.array([_check_u64("value", x) for x in values], dtype=np.uint64)
-    mn = np.array([_check_u64("min", x) for x in mins], dtype=np.uint64)
-    mx = np.array([_check_u64("max", x) for x in maxs], dtype=np.uint64)
+    v, mn, mx = _u64_array("value", values), _u64_array("min", mins), _u64_array("max", maxs)
     if not (len(mn) == n and len(mx) == n):
         raise ValueError("values, mins, maxs must have equal length")
-    cap = max_u64_for_bit_width(n_bits)
-    for i in range(n):
-        validate_range_params(int(v[i]), int(mn[i]), int(mx[i]))
-        if int(v[i]) - int(mn[i]) > cap or int(mx[i]) - int(v[i]) > cap:          # bulletproofs.rs:121-129
-            raise ZkpBackendError("Backend error: range width exceeds %d-bit capacity; use n_bits=64" % n_bits)
+    cap = np.uint64(max_u64_for_bit_width(n_bits))
+    bad = (mn > mx) | (v < mn) | (v > mx)
+    if bad.any():
+        i = int(np.argmax(bad))
+        validate_range_params(int(v[i]), int(mn[i]), int(mx[i]))                  # raises the reference's message
+    if n and (((v - mn) > cap) | ((mx - v) > cap)).any():                          # bulletproofs.rs:121-129
+        raise ZkpBackendError("Backend error: range width exceeds %d-bit capacity; use n_bits=64" % n_bits)
     if n == 0:
         return []
     L = _native.lib()
@@ -407,17 +428,8 @@ def verify_range_batch(proofs, mins, maxs):
         raise ValueError("proofs, mins, maxs must have equal length")
     if n == 0:
         return []
-    mn = np.array([_check_u64("min", x) for x in mins], dtype=np.uint64)
-    mx = np.array([_check_u64("max", x) for x in maxs], dtype=np.uint64)
-    blobs = [bytes(p) for p in proofs]
-    stride = max(16, max(len(b) for b in blobs))
-    if stride > 4096:                                   # a range envelope is 1478 bytes: anything this long is rejected outright
-        stride = 4096
-    buf = np.zeros((n, stride), dtype=np.uint8)
-    lens = np.zeros(n, dtype=np.uint32)
-    for i, b in enumerate(blobs):
-        lens[i] = len(b)                                # lengths beyond the stride are rejected by the library
-        buf[i, : min(len(b), stride)] = np.frombuffer(b[:stride], dtype=np.uint8)
+    mn, mx = _u64_array("min", mins), _u64_array("max", maxs)
+    buf, lens, stride = _rows([bytes(p) for p in proofs])      # a range envelope is 1478 bytes: anything beyond 4096 is rejected outright
     ok = np.zeros(n, dtype=np.uint8)
     rc = _native.lib().zkp_hip_verify_range_batch(n, _P(buf), stride, _P(lens), _P(mn), _P(mx), _P(ok))
     _native.check(rc, "zkp_hip_verify_range_batch")
@@ -431,14 +443,8 @@ def verify_threshold_batch(proofs, thresholds):
         raise ValueError("proofs, thresholds must have equal length")
     if n == 0:
         return []
-    th = np.array([_check_u64("threshold", x) for x in thresholds], dtype=np.uint64)
-    blobs = [bytes(p) for p in proofs]
-    stride = min(4096, max(16, max(len(b) for b in blobs)))
-    buf = np.zeros((n, stride), dtype=np.uint8)
-    lens = np.zeros(n, dtype=np.uint32)
-    for i, b in enumerate(blobs):
-        lens[i] = len(b)
-        buf[i, : min(len(b), stride)] = np.frombuffer(b[:stride], dtype=np.uint8)
+    th = _u64_array("threshold", thresholds)
+    buf, lens, stride = _rows([bytes(p) for p in proofs])
     ok = np.zeros(n, dtype=np.uint8)
     _native.check(_native.lib().zkp_hip_verify_threshold_batch(n, _P(buf), stride, _P(lens), _P(th), _P(ok)), "zkp_hip_verify_threshold_batch")
     return [x == 1 for x in ok]

@@ -16,6 +16,7 @@ struct G16Vk {
     fq12 ml_alpha_beta;            // Miller loop value of (beta, -alpha): the constant factor of the check
     uint32_t n_ic;                 // gamma_abc_g1 length (1 + public inputs)
     const uint32_t* ic;            // [n_ic][20] affine points, Montgomery limbs
+    const uint32_t* ic_table;      // optional [n_ic][26 windows][512 entries][20]: entry e of window w = (e + 1) * 1024^w * IC_i (affine)
 };
 
 ZKP_HD inline uint32_t ld_u32_le(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -79,6 +80,23 @@ ZKP_HD inline g1_aff ld_ic(const G16Vk& vk, uint32_t i) {
     for (int k = 0; k < 10; k++) { p.x.v[k] = q[k]; p.y.v[k] = q[10 + k]; }
     return p;
 }
+// k * IC_i for a raw scalar of at most 10 * nwin - 1 bits: one mixed addition per non-zero signed radix-1024 digit when the
+// key carries window tables, the generic ladder otherwise (host emulation of large keys)
+ZKP_HD_NOINLINE inline g1_jac g16_ic_mul(const G16Vk& vk, uint32_t i, const uint32_t k[8], uint32_t nwin) {
+    if (vk.ic_table == nullptr) return jac_mul_raw(jac_from_aff(ld_ic(vk, i)), k);
+    sc raw; for (int j = 0; j < 8; j++) raw.v[j] = k[j];
+    uint32_t dig[G16_DIGW]; sc_recode_signed1024(dig, raw);
+    g1_jac acc = jac_infinity<fq>();
+    for (uint32_t w = 0; w < nwin; w++) {
+        const int32_t d = (int32_t)(int16_t)(dig[w >> 1] >> (16 * (w & 1u)));
+        if (d == 0) continue;
+        const uint32_t* e = vk.ic_table + (((size_t)i * G16_NWIN + w) * G16_NENT + (uint32_t)((d < 0 ? -d : d) - 1)) * 20;
+        g1_aff q; for (int j = 0; j < 10; j++) { q.x.v[j] = e[j]; q.y.v[j] = e[10 + j]; }
+        if (d < 0) q.y = fq_neg(q.y);
+        acc = jac_madd(acc, q);
+    }
+    return acc;
+}
 // The pairing check e(A, B) e(-L, gamma) e(-C, delta) e(-alpha, beta) == 1 as its three data-dependent Miller loops:
 // pair j contributes miller_loop(Q[j], P[j]) when bit j of `present` is set (a pair with a point at infinity contributes 1);
 // bit 3: Q[0] holds a finite B whose subgroup membership is still to be checked (g16_b_in_subgroup).
@@ -108,7 +126,7 @@ ZKP_HD_NOINLINE inline bool g16_equality_pairs(const G16Vk& vk, const uint8_t* e
     if (ld_u32_le(env + 2) != 256 || ld_u32_le(env + 6) != 32) return false;
     uint32_t c[8]; ld_le_words(c, env + 266);
     if (!fr_raw_lt_r(c)) return false;
-    const g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), jac_mul_raw(jac_from_aff(ld_ic(vk, 1)), c));
+    const g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), g16_ic_mul(vk, 1, c, G16_NWIN));
     return g16_pairs(vk, env + 10, L, o);
 }
 // membership envelope (scheme 4): payload = u32 n || n x u64 set || 256-byte proof; public inputs =
@@ -122,10 +140,11 @@ ZKP_HD_NOINLINE inline bool g16_membership_pairs(const G16Vk& vk, const uint8_t*
     if (n > G16_MAX_SET || plen != 4 + 8 * n + 256) return false;
     uint32_t c[8]; ld_le_words(c, env + 10 + plen);
     if (!fr_raw_lt_r(c)) return false;
-    g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), jac_mul_raw(jac_from_aff(ld_ic(vk, 1)), c));
+    g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), g16_ic_mul(vk, 1, c, G16_NWIN));
     for (uint32_t i = 0; i < n; i++) {
         uint64_t v = 0; for (int k = 0; k < 8; k++) v |= (uint64_t)env[14 + 8 * i + k] << (8 * k);
-        if (v) L = jac_add(L, g1_mul_u64(ld_ic(vk, 2 + i), v));
+        const uint32_t vw[8] = {(uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0};
+        if (v) L = jac_add(L, vk.ic_table ? g16_ic_mul(vk, 2 + i, vw, G16_NWIN_U64) : g1_mul_u64(ld_ic(vk, 2 + i), v));
         L = jac_madd(L, ld_ic(vk, 2 + G16_MAX_SET + i));            // is_real = 1
     }
     return g16_pairs(vk, env + 14 + 8 * n, L, o);

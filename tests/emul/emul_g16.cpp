@@ -60,7 +60,26 @@ int emul_g16_verify(int kind, const uint8_t* env, uint32_t len, const uint32_t* 
     auto g2 = [](const uint32_t* w) { return g2_aff{fq2{fq_from_raw(w), fq_from_raw(w + 8)}, fq2{fq_from_raw(w + 16), fq_from_raw(w + 24)}}; };
     std::vector<uint32_t> icm((size_t)n_ic * 20);
     for (uint32_t i = 0; i < n_ic; i++) { const g1_aff p = g1(ic + 16 * i); for (int k = 0; k < 10; k++) { icm[20 * i + k] = p.x.v[k]; icm[20 * i + 10 + k] = p.y.v[k]; } }
-    G16Vk vk; vk.gamma = g2(gamma); vk.delta = g2(delta); vk.n_ic = n_ic; vk.ic = icm.data();
+    G16Vk vk; vk.gamma = g2(gamma); vk.delta = g2(delta); vk.n_ic = n_ic; vk.ic = icm.data(); vk.ic_table = nullptr;
+    // small keys (equality: two points) also get the window tables the GPU path uses, built as k_g16_build_table builds them
+    std::vector<uint32_t> tab;
+    if (n_ic <= 2) {
+        tab.resize((size_t)n_ic * G16_NWIN * G16_NENT * 20);
+        for (uint32_t i = 0; i < n_ic; i++) {
+            g1_jac q = jac_from_aff(g1(ic + 16 * i));
+            for (uint32_t w = 0; w < G16_NWIN; w++) {
+                g1_jac acc = q;
+                for (uint32_t e = 0; e < G16_NENT; e++) {
+                    g1_aff a; jac_to_aff(a, acc);
+                    uint32_t* dst = tab.data() + (((size_t)i * G16_NWIN + w) * G16_NENT + e) * 20;
+                    for (int k = 0; k < 10; k++) { dst[k] = a.x.v[k]; dst[10 + k] = a.y.v[k]; }
+                    acc = jac_add(acc, q);
+                }
+                for (uint32_t k = 0; k < G16_WBITS; k++) q = jac_dbl(q);
+            }
+        }
+        vk.ic_table = tab.data();
+    }
     vk.ml_alpha_beta = miller_loop(g2(beta), aff_neg(g1(alpha)));
     return g16_verify_envelope(kind, vk, env, len) ? 1 : 0;
 }
