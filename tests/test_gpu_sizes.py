@@ -52,6 +52,15 @@ def test_equality_sizes(hip, n):
         cs = g.equality_circuit(int(v[i]), int(v[i]), int.from_bytes(cm, "little"))
         want = g.envelope(2, g.prove_with_trapdoor(g.equality_key(SS), cs, g.draw_fr(sd, 0x47313600, 0), g.draw_fr(sd, 0x47313600, 1)), cm)
         assert out[i].tobytes() == want, (n, i)
+    # the GPU verifier over the whole oddly sized batch: all accepted; a flipped bit in A, B, C or the commitment of every third rejected
+    ok = np.zeros(n, dtype=np.uint8)
+    assert hip.zkp_hip_verify_equality_batch(n, P(out), 298, P(lens), P(ok)) == 0 and (ok == 1).all()
+    t = out.copy()
+    pos = np.array([12, 80, 210, 270])[np.arange(n) % 4]
+    t[np.arange(0, n, 3), pos[::3]] ^= 4
+    assert hip.zkp_hip_verify_equality_batch(n, P(t), 298, P(lens), P(ok)) == 0
+    want_ok = np.ones(n, dtype=np.uint8); want_ok[::3] = 0
+    assert (ok == want_ok).all()
 
 
 @pytest.mark.parametrize("n", [1, 4, 300, 1025])
