@@ -181,7 +181,8 @@ def main():
     # two output buffers), which is how a server feeding batch after batch calls the library.  Reported separately
     # because overlapped launches blur the per-launch durations the roofline is computed from.
     dt2 = None
-    if P == 1 and not args.no_overlap_leg:
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if P == 1 and not args.no_overlap_leg and not under_profiler:     # a profile of this command must hold the serial steps only
         issued[0] = 0
         step(2); step(2)
         barrier()
