@@ -47,6 +47,18 @@ while time.time() < t_end:
     if not (ok == 1).all():
         print("RANGE VERIFY FAIL it", it); sys.exit(1)
     counts["range"] += n
+    # one to three flipped bits per envelope: GPU verdicts must equal the oracle's verdicts
+    t = out.copy()
+    for _ in range(int(rng.integers(1, 4))):
+        pos = (rng.integers(0, 2**31, n) % ln).astype(np.int64)
+        t[np.arange(n), pos] ^= (1 << rng.integers(0, 8, n)).astype(np.uint8)
+    want = np.zeros(n, dtype=np.uint8)
+    oc.zkp_oracle_verify_range_batch(U64(n), P(t), U64(1478), P(ln), P(mn), P(mx), P(want), 16)
+    L.zkp_hip_verify_range_batch(n, P(t), 1478, P(ln), P(mn), P(mx), P(ok))
+    if not (ok == want).all():
+        print("TAMPER VERDICT MISMATCH it", it, "n", n, "bits", bits, np.nonzero(ok != want)[0][:5]); sys.exit(1)
+    counts["tampered"] = counts.get("tampered", 0) + n
+    counts["tampered_accepted"] = counts.get("tampered_accepted", 0) + int(want.sum())
     # ---- threshold / consistency through the Python mirror against the oracle's single-proof entry points
     m = min(n, 40)
     lists = [[int(x) for x in rng.integers(0, 2**20, int(rng.integers(1, 6)))] for _ in range(m)]
