@@ -1,7 +1,8 @@
-// libzkp_hip: kernels + C ABI (include/libzkp_hip.h) of the MI355X Bulletproofs range prover.
-// gfx950 only.  One lane = one proof for every scalar/transcript step; the dominant kernel (k_msm)
-// streams fixed-base window sub-tables through LDS so that each table byte is fetched from L2 once per
-// 256 proofs and the per-lane table gathers hit LDS instead of HBM/L2.
+// libzkp_hip: kernels + C ABI (include/libzkp_hip.h) of the MI355X Bulletproofs prover (range / threshold / consistency
+// framings, 8- to 64-bit proofs) and, through the .inc files at the end, the host side of the Groth16, STARK, verification
+// and mixed-batch entry points.  gfx950 only.  One lane = one proof for every scalar / transcript step; the dominant
+// kernel (k_msm_dma, msm_kernel.h) streams fixed-base window sub-tables through LDS by DMA so that each table byte is
+// fetched from L2 once per 1024 proofs and the per-lane table gathers hit LDS instead of HBM/L2.
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <map>
