@@ -2,8 +2,8 @@
  *
  * Drop-in boundary: these entry points are what the reference's Rust side binds through `extern "C"`
  * in place of its CPU backend calls (binding sketch: INTEGRATION.md).  Plain pointers and sizes only.
- * All calls are batch-first; a single proof is the n = 1 case.  Thread-safe: one internal context per
- * process, calls are serialised on it.
+ * All calls are batch-first; a single proof is the n = 1 case.  Thread-safe: one context ("shard") per
+ * initialised GPU, calls are serialised per shard; the batch calls drive every shard from one process.
  *
  * Randomness: the reference draws blindings from OsRng/thread_rng (bulletproofs.rs:82-87,132), so its
  * proof bytes are not reproducible.  Here every op takes a 32-byte seed from which all of its random
@@ -36,12 +36,26 @@ enum {
 #define ZKP_HIP_E_UNSUPPORTED (-2)   /* e.g. n_bits other than 8, 16, 32, 64 */
 #define ZKP_HIP_E_ARGUMENT (-3)
 
-/* One-time setup on `device`: derives the 130 Bulletproofs generators (PedersenGens::default,
+/* One-time setup on HIP device `device`: derives the 130 Bulletproofs generators (PedersenGens::default,
  * BulletproofGens::new party 0; replaces bp_gens_pair_bits, bulletproofs.rs:61-80), builds the
- * fixed-base window tables and uploads them.  Idempotent.  Called implicitly by the prove calls. */
+ * fixed-base window tables and uploads them.  Idempotent.  Called implicitly (device 0) by the prove calls.
+ * Every device initialised this way becomes one SHARD of the library (numbered in registration order). */
 int zkp_hip_init(int device);
-/* Releases every device resource (tables, loaded keys, workspaces, pooled staging buffers, streams); a later call
- * initialises again (keys must be loaded again). */
+/* Multi-GPU (replaces the rayon fan-out of batch.rs:123-131 at node scale): registers `count` shards, shard k on
+ * HIP device devices[k], each initialised by its own host thread.  One process then drives all of them:
+ * zkp_hip_process_batch / zkp_hip_batch_* cut every variant's ops into one contiguous slice per shard, and
+ * zkp_hip_groth16_load_key / _generate_key install the ONE trusted setup on every shard.  The same HIP device may be listed
+ * twice (two independent contexts; the one-GPU tests run the multi-shard path this way).  Idempotent for an identical list;
+ * any other re-registration needs zkp_hip_shutdown first. */
+int zkp_hip_init_devices(uint32_t count, const int* devices);
+int zkp_hip_device_count(void);                      /* shards registered */
+/* The per-variant entry points (everything except the batch calls below) run on ONE shard: shard 0 unless the calling
+ * thread selected another one here (thread-local; concurrent callers on different shards do not serialise). */
+int zkp_hip_use_device(int shard);
+/* Releases every device resource of every shard (tables, loaded keys, workspaces, pooled staging buffers, streams, pinned
+ * staging) and forgets the shard registration; a later call initialises again (keys must be loaded again; batches staged
+ * earlier must be staged again).  Registered with atexit() at the first initialisation, so the HIP runtime never finds live
+ * objects of this library during its own exit-time teardown. */
 void zkp_hip_shutdown(void);
 /* Thread-local description of the last failure of a call made on this thread. */
 const char* zkp_hip_last_error(void);
@@ -172,12 +186,29 @@ typedef struct zkp_hip_op {
 } zkp_hip_op;
 int zkp_hip_process_batch(uint64_t n, const zkp_hip_op* ops, const uint64_t* lists, const uint8_t* seeds,
                           uint8_t* out, uint64_t out_cap, uint64_t* out_off, int32_t* status);
+/* Capacity that is enough for any outcome of zkp_hip_process_batch on these ops (improvement envelopes counted at
+ * zkp_hip_improvement_max_bytes()): callers size `out` with it instead of proving twice.  No device work. */
+int zkp_hip_process_batch_bytes(uint64_t n, const zkp_hip_op* ops, uint64_t* max_total);
+
+/* The three phases of zkp_hip_process_batch as separate calls.  A staged batch is the device-side counterpart of the
+ * reference's ProofBatch (composition.rs:337-413, filled by batch_add_*, batch.rs:40-108): ops bucketed by variant, validated
+ * (validation.rs), cut into per-shard slices and uploaded, i.e. resident in HBM.  zkp_hip_batch_prove runs the whole batch on
+ * every shard (variants on their own streams, proofs packed in op order on the device) and waits; it may be repeated.
+ * zkp_hip_batch_fetch copies the proofs out exactly as zkp_hip_process_batch returns them (same return values). */
+typedef struct zkp_hip_batch zkp_hip_batch;
+int zkp_hip_batch_stage(uint64_t n, const zkp_hip_op* ops, const uint64_t* lists, const uint8_t* seeds, zkp_hip_batch** batch);
+int zkp_hip_batch_prove(zkp_hip_batch* batch);
+uint64_t zkp_hip_batch_max_bytes(const zkp_hip_batch* batch);
+int zkp_hip_batch_fetch(zkp_hip_batch* batch, uint8_t* out, uint64_t out_cap, uint64_t* out_off, int32_t* status);
+void zkp_hip_batch_free(zkp_hip_batch* batch);
 
 /* Kernel timing for the roofline line of bench.py: when enabled, every launch of the dominant kernel
  * (fixed-base MSM) is bracketed by hipEvents on its own stream. */
 void zkp_hip_profile_enable(int on);
 /* Synchronises, then returns accumulated MSM kernel time (ms), launch count, and table-entry gathers
- * (point additions) since the last reset. */
+ * (point additions) since the last reset, summed over the shards.  zkp_hip_profile_read is kernel 0. */
+enum { ZKP_HIP_KERNEL_MSM_ED25519 = 0, ZKP_HIP_KERNEL_MSM_BN254_G1 = 1, ZKP_HIP_KERNEL_MSM_BN254_G2 = 2 };
+int zkp_hip_profile_read_kernel(int which, double* ms, uint64_t* launches, uint64_t* point_adds, int reset);
 int zkp_hip_profile_read(double* msm_ms, uint64_t* msm_launches, uint64_t* msm_point_adds, int reset);
 /* Tunables (benchmarking).  window budget: 0 = chunking chosen per launch from the batch size (default); 32*T = slot-aligned
  * chunks of 32*T windows; 10000 + c = the window-granular layout with about c chunks.  sub-batches: independent slices

@@ -2,6 +2,7 @@
 
 There is deliberately no fallback: if the shared library is missing or no MI355X is present the calls raise.
 """
+import atexit
 import ctypes
 import os
 
@@ -17,6 +18,8 @@ EXPORTS = (
     "zkp_hip_prove_equality_batch", "zkp_hip_prove_membership_batch", "zkp_hip_improvement_max_bytes", "zkp_hip_prove_improvement_batch",
     "zkp_hip_prove_improvement_batch_device", "zkp_hip_verify_range_batch", "zkp_hip_verify_threshold_batch", "zkp_hip_verify_consistency_batch", "zkp_hip_verify_equality_batch", "zkp_hip_verify_membership_batch",
     "zkp_hip_verify_improvement_batch", "zkp_hip_process_batch", "zkp_hip_profile_enable", "zkp_hip_profile_read", "zkp_hip_set_window_budget", "zkp_hip_set_subbatches", "zkp_hip_set_msm_variant",
+    "zkp_hip_init_devices", "zkp_hip_device_count", "zkp_hip_use_device", "zkp_hip_process_batch_bytes", "zkp_hip_batch_stage", "zkp_hip_batch_prove", "zkp_hip_batch_max_bytes",
+    "zkp_hip_batch_fetch", "zkp_hip_batch_free", "zkp_hip_profile_read_kernel",
 )
 
 _lib = None
@@ -115,8 +118,37 @@ def lib():
         L.zkp_hip_set_subbatches.restype = None
         L.zkp_hip_set_msm_variant.argtypes = [u32]
         L.zkp_hip_set_msm_variant.restype = None
+        L.zkp_hip_init_devices.argtypes = [u32, ctypes.POINTER(ctypes.c_int)]
+        L.zkp_hip_init_devices.restype = ctypes.c_int
+        L.zkp_hip_device_count.argtypes = []
+        L.zkp_hip_device_count.restype = ctypes.c_int
+        L.zkp_hip_use_device.argtypes = [ctypes.c_int]
+        L.zkp_hip_use_device.restype = ctypes.c_int
+        L.zkp_hip_process_batch_bytes.argtypes = [u64, vp, ctypes.POINTER(u64)]
+        L.zkp_hip_process_batch_bytes.restype = ctypes.c_int
+        L.zkp_hip_batch_stage.argtypes = [u64, vp, vp, vp, ctypes.POINTER(vp)]
+        L.zkp_hip_batch_stage.restype = ctypes.c_int
+        L.zkp_hip_batch_prove.argtypes = [vp]
+        L.zkp_hip_batch_prove.restype = ctypes.c_int
+        L.zkp_hip_batch_max_bytes.argtypes = [vp]
+        L.zkp_hip_batch_max_bytes.restype = u64
+        L.zkp_hip_batch_fetch.argtypes = [vp, vp, u64, vp, vp]
+        L.zkp_hip_batch_fetch.restype = ctypes.c_int
+        L.zkp_hip_batch_free.argtypes = [vp]
+        L.zkp_hip_batch_free.restype = None
+        L.zkp_hip_profile_read_kernel.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.c_int]
+        L.zkp_hip_profile_read_kernel.restype = ctypes.c_int
+        # Release every device object while the interpreter and the HIP runtime are still fully alive (the library also
+        # registers its own C atexit hook at the first initialisation; both are idempotent).  DESIGN.md "exit-time teardown".
+        atexit.register(L.zkp_hip_shutdown)
         _lib = L
     return _lib
+
+
+def init_devices(devices):
+    """zkp_hip_init_devices: shard k of the library on HIP device devices[k] (one process drives them all)."""
+    arr = (ctypes.c_int * len(devices))(*devices)
+    return check(lib().zkp_hip_init_devices(len(devices), arr), "zkp_hip_init_devices")
 
 
 def last_error():

@@ -3,6 +3,7 @@
 // MembershipCircuit::generate_constraints (:514-585) and mimc_hash_circuit (:232-247) including the allocation order of
 // instance and witness variables.  One-time setup data; witness VALUES are produced on the GPU (g16_steps.h).
 #pragma once
+#include <mutex>
 #include <array>
 #include <map>
 #include <vector>
@@ -48,14 +49,16 @@ inline uint32_t r1cs_mul(HostR1CS& cs, const HostLC& a, const HostLC& b, uint8_t
 inline void r1cs_enforce_equal(HostR1CS& cs, const HostLC& a, const HostLC& b) { cs.rows.push_back({lc_sub(a, b), lc_var(VAR_ONE), HostLC{}}); }
 
 inline std::vector<fr> g_mimc_host;     // round constants, snark.rs:186-199
-inline void ensure_mimc_constants() {
-    if (!g_mimc_host.empty()) return;
-    for (uint32_t i = 0; i < MIMC_ROUNDS; i++) {
-        uint8_t in[23]; memcpy(in, "libzkp_mimc_v1:", 15); for (int k = 0; k < 8; k++) in[15 + k] = (uint8_t)((uint64_t)i >> (8 * k));
-        uint8_t h[32]; sha256_host(h, in, 23);
-        uint32_t w[8]; memcpy(w, h, 32);
-        g_mimc_host.push_back(fp_from_raw<FrParams>(w));     // from_le_bytes_mod_order
-    }
+inline std::once_flag g_mimc_once;
+inline void ensure_mimc_constants() {       // thread-safe: shards load their keys from parallel host threads
+    std::call_once(g_mimc_once, []() {
+        for (uint32_t i = 0; i < MIMC_ROUNDS; i++) {
+            uint8_t in[23]; memcpy(in, "libzkp_mimc_v1:", 15); for (int k = 0; k < 8; k++) in[15 + k] = (uint8_t)((uint64_t)i >> (8 * k));
+            uint8_t h[32]; sha256_host(h, in, 23);
+            uint32_t w[8]; memcpy(w, h, 32);
+            g_mimc_host.push_back(fp_from_raw<FrParams>(w));     // from_le_bytes_mod_order
+        }
+    });
 }
 inline HostLC r1cs_mimc(HostR1CS& cs, HostLC x) {                   // snark.rs:232-247
     ensure_mimc_constants();

@@ -131,15 +131,15 @@ void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uin
     if (!g2) k_g16_build_table<fq, 20><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table);
     else k_g16_build_table<fq2, 40><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table);
 }
+// > 64 KB of dynamic LDS needs the opt-in attribute; once per HIP device (called when a shard creates its Groth16 state)
+hipError_t g16_prepare_device() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<G1Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<G1Msm>());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<G2Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<G2Msm>());
+}
 void g16_launch_msm(bool g2, const MsmView& m, hipStream_t st) {
     const uint32_t tb = g2 ? G2Msm::TB : G1Msm::TB;
     const uint32_t ngroups = (m.rows + tb - 1) / tb, nblocks = m.nchunks * ngroups, grid = ((nblocks + 7) / 8) * 8;
-    static bool attr_set = false;
-    if (!attr_set) {       // > 64 KB of dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<G1Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<G1Msm>());
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<G2Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<G2Msm>());
-        attr_set = true;
-    }
     if (!g2) k_msm_dma<G1Msm><<<grid, G1Msm::TB, msm_lds_bytes<G1Msm>(), st>>>(m, ngroups, nblocks);
     else k_msm_dma<G2Msm><<<grid, G2Msm::TB, msm_lds_bytes<G2Msm>(), st>>>(m, ngroups, nblocks);
 }

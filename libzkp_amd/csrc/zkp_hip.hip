@@ -5,6 +5,8 @@
 // fetched from L2 once per 1024 proofs and the per-lane table gathers hit LDS instead of HBM/L2.
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <memory>
+#include <algorithm>
 #include <map>
 #include <array>
 #include <type_traits>
@@ -191,17 +193,18 @@ struct DevPool {
     }
     void release_all() { std::lock_guard<std::mutex> lk(mu); trim_locked(0); }
 };
-DevPool g_pool;
-void dev_scope_quiesce();       // waits for the library's own stream: a block must be idle before it goes back to the pool
+DevPool& dev_pool();            // the pool of the shard the calling thread is bound to
+void dev_scope_quiesce();       // waits for that shard's own stream: a block must be idle before it goes back to the pool
 struct DevScope {
     std::vector<void*> owned;
     DevScope() = default;
     DevScope(const DevScope&) = delete;
     DevScope& operator=(const DevScope&) = delete;
-    ~DevScope() { if (!owned.empty()) dev_scope_quiesce(); for (void* q : owned) g_pool.give(q); }
+    ~DevScope() { release(); }
+    void release() { if (!owned.empty()) dev_scope_quiesce(); for (void* q : owned) dev_pool().give(q); owned.clear(); }
     template <class T> hipError_t alloc(T** out, size_t bytes) {
         void* q = nullptr;
-        const hipError_t e = g_pool.take(&q, bytes ? bytes : 1);
+        const hipError_t e = dev_pool().take(&q, bytes ? bytes : 1);
         if (e == hipSuccess) owned.push_back(q);
         *out = static_cast<T*>(q);
         return e;
@@ -231,9 +234,17 @@ struct SubBatch {
 constexpr uint32_t NSLOTS = 2;      // device-pointer calls alternate between two sets of streams + workspace, so a caller that
                                     // feeds batches from two of its own streams keeps two batches in flight (bench.py --pipeline 2)
 
-struct Ctx {
+// One shard = one HIP device context of the library: tables, workspaces, streams, loaded keys.  The registry maps shard
+// numbers to HIP devices (the same HIP device may back two shards: two independent contexts, which is how the one-GPU
+// tests exercise the multi-GPU path).  Each ABI call binds the calling thread to one shard (`Bind`) and holds that shard's
+// mutex; calls on different shards run concurrently, and zkp_hip_process_batch / the staged-batch entry points drive
+// every shard from one host worker thread each (batch_impl.inc).
+struct G16State; struct StarkState; struct VfyState; struct BatchState;
+struct Device {
+    int index = 0, hip_dev = 0;
+    std::mutex mu;
     bool ready = false;
-    int device = 0;
+    uint64_t generation = 0;            // bumped by zkp_hip_shutdown: staged batches of an earlier life own nothing any more
     int num_cu = 256, msm_blocks_per_cu = 3;
     hipStream_t stream = nullptr;
     uint32_t* d_table = nullptr;
@@ -245,18 +256,51 @@ struct Ctx {
     uint32_t max_chunks = 0;
     std::vector<SubBatch> sub;          // [slot * nsub + h]
     uint32_t nsub = 1, next_slot = 0;
-    // profiling
+    DevPool pool;
+    // the other parts of the library keep their per-shard state behind these (created on first use, freed by shutdown)
+    G16State* g16 = nullptr; StarkState* stark = nullptr; VfyState* vfy = nullptr; BatchState* batch = nullptr;
+    // profiling (bench.py's roofline): every launch of the three MSM kernels bracketed by events on its own stream
     bool profiling = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    size_t ev_used = 0;
-    double msm_ms = 0; uint64_t msm_launches = 0, msm_adds = 0;
+    struct KProf {
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool; size_t ev_used = 0;
+        double ms = 0; uint64_t launches = 0, adds = 0;
+    };
+    KProf prof[3];                      // ZKP_HIP_KERNEL_MSM_ED25519 / _BN254_G1 / _BN254_G2
 };
-Ctx g;
-std::mutex g_mu;
-void dev_scope_quiesce() { if (g.stream) (void)hipStreamSynchronize(g.stream); }
+// event pair around one profiled launch (nullptrs when profiling is off)
+int prof_begin(Device::KProf& K, hipStream_t st, hipEvent_t* e1);
+void prof_end(Device::KProf& K, hipStream_t st, hipEvent_t e1, uint64_t adds);
+// Everything below is allocated once and never destroyed: no destructor of this library runs from exit() (the HIP
+// runtime and profiler tools tear themselves down there in an order we do not control); device resources are released
+// by zkp_hip_shutdown, which an atexit hook registered at the first initialisation calls while the runtime is alive.
+struct Registry {
+    std::mutex mu;
+    std::vector<Device*> shards;
+    std::shared_ptr<std::vector<uint32_t>> host_table;      // generator window tables, kept while several shards initialise
+    bool hooked = false;
+};
+Registry& registry() { static Registry* r = new Registry(); return *r; }
+thread_local Device* t_dev = nullptr;      // shard the calling thread is bound to for the duration of an ABI call
+thread_local int t_sel = 0;                // shard the per-variant entry points of this thread use (zkp_hip_use_device)
+Device& dev() { return *t_dev; }
+DevPool& dev_pool() { return dev().pool; }
+void dev_scope_quiesce() { if (dev().stream) (void)hipStreamSynchronize(dev().stream); }
 uint32_t g_budget_request = 0;     // 0 = choose per launch
 double g_fill = 1.0;               // benchmarking knob: scales the resident-workgroup count the Bulletproofs MSM chunking aims at
 uint32_t g_subbatches = 1;         // >1: independent slices on separate streams (measured slower on MI355X: see DESIGN.md)
+
+int prof_begin(Device::KProf& K, hipStream_t st, hipEvent_t* e1) {
+    *e1 = nullptr;
+    if (!dev().profiling) return 0;
+    if (K.ev_used == K.ev_pool.size()) { hipEvent_t a, b; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b)); K.ev_pool.push_back({a, b}); }
+    HIP_TRY(hipEventRecord(K.ev_pool[K.ev_used].first, st));
+    *e1 = K.ev_pool[K.ev_used].second; K.ev_used++;
+    return 0;
+}
+void prof_end(Device::KProf& K, hipStream_t st, hipEvent_t e1, uint64_t adds) {
+    if (!e1) return;
+    (void)hipEventRecord(e1, st); K.launches++; K.adds += adds;
+}
 
 int upload_layout(DevLayout& D, const MsmLayout& L) {
     D.nslots = L.nslots(); D.nchunks = L.nchunks(); D.ntargets = L.ntargets();
@@ -299,7 +343,7 @@ int upload_set(LayoutSet& S, const std::vector<SlotList>& targets) {
     for (uint32_t c : counts) { if (c > total || c < targets.size()) continue; int rc = push(make_layout_even(targets, c)); if (rc) return rc; }
     return 0;
 }
-void free_set(LayoutSet& S) { for (auto& d : S.cand) free_layout(d); S.cand.clear(); }
+void free_set(LayoutSet& S) { for (auto& d : S.cand) free_layout(d); S.cand.clear(); S.max_chunks = 0; }
 
 // Chunk size for one launch: the grid is nchunks * ceil(rows/256) workgroups, msm_blocks_per_cu * num_cu of which are
 // resident at a time; cost = (#rounds of resident workgroups) * (windows per workgroup) + the serial partial-sum tail.
@@ -314,7 +358,7 @@ const DevLayout& pick_layout(const LayoutSet& S, uint32_t rows) {
     // workgroups (measured: 1.5 rounds cost 1.30x of 1 round, 2 rounds 1.00x with half-size chunks).  Take the window-
     // granular layout that minimises rounds x (windows per workgroup + per-workgroup overhead) + the partial-sum work
     // that grows with the chunk count; g_fill scales the resident count (benchmarking knob, default 1).
-    const double resident = g_fill * (double)g.num_cu * g.msm_blocks_per_cu;
+    const double resident = g_fill * (double)dev().num_cu * dev().msm_blocks_per_cu;
     const uint32_t groups = (rows + EdMsm::TB - 1) / EdMsm::TB;
     size_t best = MAXT; double best_cost = 1e300;
     for (size_t i = MAXT; i < S.cand.size(); i++) {
@@ -328,13 +372,13 @@ const DevLayout& pick_layout(const LayoutSet& S, uint32_t rows) {
 
 // chunkings of the launches whose generator set depends on the bit width (lg = log2 n, 3..6)
 int ensure_family(uint32_t lg) {
-    Ctx::Family& F = g.fam[lg - 3];
+    Device::Family& F = dev().fam[lg - 3];
     if (F.ready) return 0;
     int rc;
     if ((rc = upload_set(F.p1, targets_phase1(1u << lg)))) return rc;
     for (uint32_t r = 0; r < lg; r++) if ((rc = upload_set(F.rd[r], targets_round(r, 1u << lg)))) return rc;
-    if (F.p1.max_chunks > g.max_chunks) g.max_chunks = F.p1.max_chunks;
-    for (uint32_t r = 0; r < lg; r++) if (F.rd[r].max_chunks > g.max_chunks) g.max_chunks = F.rd[r].max_chunks;
+    if (F.p1.max_chunks > dev().max_chunks) dev().max_chunks = F.p1.max_chunks;
+    for (uint32_t r = 0; r < lg; r++) if (F.rd[r].max_chunks > dev().max_chunks) dev().max_chunks = F.rd[r].max_chunks;
     F.ready = true;
     return 0;
 }
@@ -343,49 +387,52 @@ bool bits_to_lg(uint32_t n_bits, uint32_t* lg) {     // RangeProof::prove_single
     return false;
 }
 
-int init_locked(int device) {
-    if (g.ready) {
-        if (device != g.device) return fail(ZKP_HIP_E_ARGUMENT, "zkp_hip_init: already initialised on another device");
-        return 0;
-    }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-        return fail(ZKP_HIP_E_RUNTIME, "zkp_hip_init: no HIP device available (this library has no CPU fallback)");
-    if (device < 0 || device >= ndev) return fail(ZKP_HIP_E_ARGUMENT, "zkp_hip_init: bad device index");
-    HIP_TRY(hipSetDevice(device));
-    g.device = device;
-    hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, device));
-    g.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+// generator window tables (one-time, host; shared by every shard)
+std::shared_ptr<std::vector<uint32_t>> host_generator_tables() {
+    Registry& R = registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    if (R.host_table) return R.host_table;
+    const size_t words = (size_t)NBASE * NWIN * SUBTAB_W;
+    auto tab = std::make_shared<std::vector<uint32_t>>(words);
+    ge gens[NBASE]; host_generators(gens);
+    std::atomic<int> next{0};
+    auto work = [&]() { for (int b; (b = next.fetch_add(1)) < (int)NBASE;) host_build_table_for_base(tab->data() + (size_t)b * NWIN * SUBTAB_W, gens[b]); };
+    unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 16) nt = 16;
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    R.host_table = tab;
+    return tab;
+}
+void drop_host_generator_tables() { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); R.host_table.reset(); }
+
+// brings the bound shard up (caller holds its mutex and has made its HIP device current)
+int init_device() {
+    Device& D = dev();
+    if (D.ready) return 0;
+    hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, D.hip_dev));
+    D.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     int occ = 0;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<EdMsm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<EdMsm>()));
-    g.msm_blocks_per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_msm_dma<EdMsm>, EdMsm::TB, msm_lds_bytes<EdMsm>()) == hipSuccess && occ > 0) g.msm_blocks_per_cu = occ;
-    HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    // generator tables (one-time, host)
-    const size_t words = (size_t)NBASE * NWIN * SUBTAB_W;
-    std::vector<uint32_t> tab(words);
-    ge gens[NBASE]; host_generators(gens);
+    D.msm_blocks_per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_msm_dma<EdMsm>, EdMsm::TB, msm_lds_bytes<EdMsm>()) == hipSuccess && occ > 0) D.msm_blocks_per_cu = occ;
+    HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
     {
-        std::atomic<int> next{0};
-        auto work = [&]() { for (int b; (b = next.fetch_add(1)) < (int)NBASE;) host_build_table_for_base(tab.data() + (size_t)b * NWIN * SUBTAB_W, gens[b]); };
-        unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 16) nt = 16;
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
-        work();
-        for (auto& th : pool) th.join();
+        const auto tab = host_generator_tables();
+        HIP_TRY(hipMalloc(&D.d_table, tab->size() * 4));
+        HIP_TRY(hipMemcpy(D.d_table, tab->data(), tab->size() * 4, hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMalloc(&g.d_table, words * 4));
-    HIP_TRY(hipMemcpy(g.d_table, tab.data(), words * 4, hipMemcpyHostToDevice));
     int rc;
-    g.max_chunks = 0;
-    if ((rc = upload_set(g.p2, targets_phase2()))) return rc;
-    if ((rc = upload_set(g.ct, targets_ctask()))) return rc;
-    g.max_chunks = g.p2.max_chunks;
+    D.max_chunks = 0;
+    if ((rc = upload_set(D.p2, targets_phase2()))) return rc;
+    if ((rc = upload_set(D.ct, targets_ctask()))) return rc;
+    D.max_chunks = D.p2.max_chunks;
     if ((rc = ensure_family(6))) return rc;
     uint32_t ns = g_subbatches; if (ns < 1) ns = 1; if (ns > 8) ns = 8;
-    g.nsub = ns;
-    g.sub.resize((size_t)NSLOTS * ns);
-    for (auto& sb : g.sub) {
+    D.nsub = ns;
+    D.sub.resize((size_t)NSLOTS * ns);
+    for (auto& sb : D.sub) {
         HIP_TRY(hipStreamCreateWithFlags(&sb.stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&sb.side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&sb.start, hipEventDisableTiming));
@@ -393,9 +440,51 @@ int init_locked(int device) {
         HIP_TRY(hipEventCreateWithFlags(&sb.side_go, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sb.side_done, hipEventDisableTiming));
     }
-    g.ready = true;
+    D.ready = true;
     return 0;
 }
+
+extern "C" void zkp_hip_shutdown(void);
+void batch_release_all();
+void stark_release_all();
+// shard `index` of the registry; registers shard 0 on HIP device 0 when nothing has been registered yet
+int find_shard(int index, Device** out) {
+    Registry& R = registry();
+    std::lock_guard<std::mutex> lk(R.mu);
+    if (R.shards.empty()) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            return fail(ZKP_HIP_E_RUNTIME, "zkp_hip_init: no HIP device available (this library has no CPU fallback)");
+        Device* d = new Device(); d->index = 0; d->hip_dev = 0; R.shards.push_back(d);
+    }
+    if (!R.hooked) { R.hooked = true; (void)atexit(zkp_hip_shutdown); }
+    if (index < 0 || index >= (int)R.shards.size()) return fail(ZKP_HIP_E_ARGUMENT, "no such device shard (zkp_hip_init / zkp_hip_init_devices register them)");
+    *out = R.shards[index];
+    return 0;
+}
+// Binds the calling thread to one shard for the duration of an ABI call: takes the shard's mutex, makes its HIP device
+// current and initialises it on first use.  Calls nest on one thread only through `Bind::adopt` (worker threads of a
+// multi-shard batch bind their own shard).
+struct Bind {
+    std::unique_lock<std::mutex> lk;
+    Device* prev = nullptr; bool bound = false;
+    Bind() = default;
+    Bind(const Bind&) = delete;
+    Bind& operator=(const Bind&) = delete;
+    int open(int shard = -1) {
+        Device* d = nullptr;
+        int rc = find_shard(shard < 0 ? t_sel : shard, &d);
+        if (rc) return rc;
+        return open(d);
+    }
+    int open(Device* d, bool init = true) {
+        lk = std::unique_lock<std::mutex>(d->mu);
+        prev = t_dev; t_dev = d; bound = true;
+        HIP_TRY(hipSetDevice(d->hip_dev));
+        return init ? init_device() : 0;
+    }
+    ~Bind() { if (bound) t_dev = prev; }
+};
 
 // workspace carving ---------------------------------------------------------------------------------
 struct Ws {
@@ -428,7 +517,7 @@ size_t carve(uint8_t* base, uint32_t M, uint32_t C, uint32_t max_chunks, Ws* w) 
     t.sums = (uint32_t*)take((size_t)3 * GE_W * 4 * M);
     t.T.C = C; t.T.v = t.J.ct_v; t.T.seed_ix = t.J.ct_seed_ix; t.T.bl_ix = t.J.ct_bl_ix;
     t.T.digits = (uint32_t*)take((size_t)2 * DIGW * 4 * C);
-    t.ct_partial = (uint32_t*)take((size_t)(g.ct.max_chunks ? g.ct.max_chunks : 2) * GE_W * 4 * C);
+    t.ct_partial = (uint32_t*)take((size_t)(dev().ct.max_chunks ? dev().ct.max_chunks : 2) * GE_W * 4 * C);
     t.ct_enc = (uint32_t*)take((size_t)8 * 4 * C);
     t.ct_sums = (uint32_t*)take((size_t)GE_W * 4 * C);
     t.ct_off = t.J.ct_off;
@@ -438,30 +527,25 @@ size_t carve(uint8_t* base, uint32_t M, uint32_t C, uint32_t max_chunks, Ws* w) 
 }
 
 int ensure_workspace(SubBatch& sb, uint32_t M, uint32_t C) {
-    if (M <= sb.capM && C <= sb.capC && g.max_chunks <= sb.cap_chunks && sb.ws) return 0;
+    if (M <= sb.capM && C <= sb.capC && dev().max_chunks <= sb.cap_chunks && sb.ws) return 0;
     if (sb.ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(sb.ws)); sb.ws = nullptr; }
     const uint32_t nm = M > sb.capM ? M : sb.capM, nc = C > sb.capC ? C : sb.capC;
-    const size_t bytes = carve(nullptr, nm, nc, g.max_chunks, nullptr);
+    const size_t bytes = carve(nullptr, nm, nc, dev().max_chunks, nullptr);
     HIP_TRY(hipMalloc(&sb.ws, bytes));
-    sb.capM = nm; sb.capC = nc; sb.cap_chunks = g.max_chunks;
+    sb.capM = nm; sb.capC = nc; sb.cap_chunks = dev().max_chunks;
     return 0;
 }
 
 int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32_t* partial, hipStream_t st) {
-    MsmView m; m.rows = rows; m.nslots = D.nslots; m.nchunks = D.nchunks; m.table = g.d_table; m.digits = digits;
+    MsmView m; m.rows = rows; m.nslots = D.nslots; m.nchunks = D.nchunks; m.table = dev().d_table; m.digits = digits;
     m.slot_base = D.slot_base; m.slot_scalar = nullptr; m.slot_nwin = D.slot_nwin; m.chunk_begin = D.chunk_begin; m.chunk_win0 = D.chunk_win0; m.chunk_nwin = D.chunk_nwin; m.partial = partial; m.acc_init = nullptr;
     const uint32_t ngroups = (rows + EdMsm::TB - 1) / EdMsm::TB, nblocks = D.nchunks * ngroups;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (g.profiling) {
-        if (g.ev_used == g.ev_pool.size()) {
-            hipEvent_t a, b; HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b)); g.ev_pool.push_back({a, b});
-        }
-        e0 = g.ev_pool[g.ev_used].first; e1 = g.ev_pool[g.ev_used].second; g.ev_used++;
-        HIP_TRY(hipEventRecord(e0, st));
-    }
+    hipEvent_t e1 = nullptr;
+    int rc = prof_begin(dev().prof[0], st, &e1);
+    if (rc) return rc;
     k_msm_dma<EdMsm><<<grid, EdMsm::TB, msm_lds_bytes<EdMsm>(), st>>>(m, ngroups, nblocks);
-    if (g.profiling) { HIP_TRY(hipEventRecord(e1, st)); g.msm_launches++; g.msm_adds += D.adds_per_row * rows; }
+    prof_end(dev().prof[0], st, e1, D.adds_per_row * rows);
     return 0;
 }
 int launch_reduce(const DevLayout& D, uint32_t rows, const uint32_t* partial, uint32_t* sums, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
@@ -483,7 +567,7 @@ int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st, SubBatch& 
     int rc;
     const dim3 gj((M + TB - 1) / TB), gw((M + TW - 1) / TW);
     const uint32_t n = w.V.n, lg = w.V.lg;
-    const Ctx::Family& F = g.fam[lg - 3];
+    const Device::Family& F = dev().fam[lg - 3];
     // The commitment tasks (one small MSM, one inverse-square-root chain on C/64 waves) depend on nothing the proofs compute:
     // they go to a side stream and overlap the tape / first MSM instead of standing in front of them.
     const bool forked = C != 0 && M != 0;
@@ -491,7 +575,7 @@ int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st, SubBatch& 
         hipStream_t cs = forked ? lane.side : st;
         if (forked) { HIP_TRY(hipEventRecord(lane.side_go, st)); HIP_TRY(hipStreamWaitEvent(cs, lane.side_go, 0)); }
         k_ctask<<<(C + TB - 1) / TB, TB, 0, cs>>>(w.T);
-        if ((rc = msm_and_encode(g.ct, C, w.T.digits, w.ct_partial, w.ct_sums, w.ct_enc, w.ct_off, w.V.out, cs))) return rc;
+        if ((rc = msm_and_encode(dev().ct, C, w.T.digits, w.ct_partial, w.ct_sums, w.ct_enc, w.ct_off, w.V.out, cs))) return rc;
         if (forked) HIP_TRY(hipEventRecord(lane.side_done, cs));
     }
     if (M == 0) { HIP_TRY(hipGetLastError()); return 0; }
@@ -500,7 +584,7 @@ int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st, SubBatch& 
     k_transcript1<<<gw, TW, 0, st>>>(w.V);
     k_poly<<<dim3(gj.x, n), TB, 0, st>>>(w.V);
     k_poly_sum<<<(M + 7) / 8, TW, 0, st>>>(w.V);
-    if ((rc = msm_and_encode(g.p2, M, w.V.d2, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
+    if ((rc = msm_and_encode(dev().p2, M, w.V.d2, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
     k_transcript2<<<gw, TW, 0, st>>>(w.V);
     k_lr_init<<<dim3(gj.x, n), TB, 0, st>>>(w.V);
     for (uint32_t r = 0; r < lg; r++) {
@@ -530,19 +614,19 @@ int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_
     if (stride < range_envelope_bytes(lg)) return fail(ZKP_HIP_E_ARGUMENT, "stride is smaller than the proof (1478 bytes for n_bits = 64)");
     int rc;
     if ((rc = ensure_family(lg))) return rc;
-    uint32_t nsub = g.nsub;
+    uint32_t nsub = dev().nsub;
     if (n < 512) nsub = 1;                       // small batches: one stream
     const uint64_t per = (n + nsub - 1) / nsub;
-    const uint32_t slot = g.next_slot; g.next_slot = (g.next_slot + 1) % NSLOTS;
-    SubBatch& first = g.sub[(size_t)slot * g.nsub];
+    const uint32_t slot = dev().next_slot; dev().next_slot = (dev().next_slot + 1) % NSLOTS;
+    SubBatch& first = dev().sub[(size_t)slot * dev().nsub];
     HIP_TRY(hipEventRecord(first.start, st));
     for (uint32_t h = 0; h < nsub; h++) {
         const uint64_t lo = h * per, hi = (lo + per < n) ? lo + per : n;
         if (lo >= hi) continue;
-        SubBatch& sb = g.sub[(size_t)slot * g.nsub + h];
+        SubBatch& sb = dev().sub[(size_t)slot * dev().nsub + h];
         const uint32_t C = (uint32_t)(hi - lo), M = 2 * C;
         if ((rc = ensure_workspace(sb, M, C))) return rc;
-        Ws w; carve((uint8_t*)sb.ws, M, C, g.max_chunks, &w);
+        Ws w; carve((uint8_t*)sb.ws, M, C, dev().max_chunks, &w);
         w.V.n = 1u << lg; w.V.lg = lg;
         w.V.seeds = reinterpret_cast<const uint32_t*>(d_seeds + 32 * lo); w.T.seeds = w.V.seeds;
         w.V.out = d_out + lo * stride;
@@ -553,7 +637,7 @@ int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_
         HIP_TRY(hipStreamWaitEvent(st, sb.done, 0));
     }
     if (any_failed) {
-        Ws w; carve((uint8_t*)first.ws, first.capM, first.capC, g.max_chunks, &w);
+        Ws w; carve((uint8_t*)first.ws, first.capM, first.capC, dev().max_chunks, &w);
         HIP_TRY(hipMemsetAsync(w.flag, 0, sizeof(int), st));
         k_any_failed<<<(uint32_t)((n + TB - 1) / TB), TB, 0, st>>>(d_status, (uint32_t)n, w.flag);
         HIP_TRY(hipMemcpyAsync(any_failed, w.flag, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -577,33 +661,40 @@ struct HostJobs {
     void add_commit(uint64_t val, uint32_t seed, uint32_t bl, uint64_t off) { ct_v.push_back(val); ct_seed_ix.push_back(seed); ct_bl_ix.push_back(bl); ct_off.push_back(off); }
 };
 
-// out: host buffer already holding every framing byte; proofs and commitments are filled in by the device
-int run_host_jobs(const HostJobs& H, const uint8_t* seeds, size_t nseeds, uint8_t* out, size_t out_bytes, uint32_t lg = 6) {
+// Uploads a host-built job list into the workspace of `sb` and runs the prover on `st`.  d_img: device image that already
+// holds every framing byte (proof_off / commit_off / ct_off are offsets into it); d_seeds: 32 bytes per seed index.
+// The job arrays of H must stay alive until `st` has passed the copies (callers keep H until they synchronise).
+int run_jobs_on(SubBatch& sb, const HostJobs& H, const uint8_t* d_seeds, uint8_t* d_img, uint32_t lg, hipStream_t st) {
     const uint32_t M = (uint32_t)H.v.size(), C = (uint32_t)H.ct_v.size();
     if (M == 0 && C == 0) return 0;
     int rc;
     if ((rc = ensure_family(lg))) return rc;
-    SubBatch& sb = g.sub[0];
-    hipStream_t st = g.stream;
     if (sb.used) HIP_TRY(hipStreamWaitEvent(st, sb.done, 0));          // an asynchronous device-pointer call may still own this workspace
     if ((rc = ensure_workspace(sb, M ? M : 1, C ? C : 1))) return rc;
-    Ws w; carve((uint8_t*)sb.ws, M ? M : 1, C ? C : 1, g.max_chunks, &w);
+    Ws w; carve((uint8_t*)sb.ws, M ? M : 1, C ? C : 1, dev().max_chunks, &w);
     w.V.M = M; w.T.C = C; w.V.n = 1u << lg; w.V.lg = lg;
-    DevScope mem;
-    uint8_t *d_seeds = nullptr, *d_out = nullptr;
-    HIP_TRY(mem.alloc(&d_seeds, 32 * nseeds)); HIP_TRY(mem.alloc(&d_out, out_bytes));
-    HIP_TRY(hipMemcpyAsync(d_seeds, seeds, 32 * nseeds, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_out, out, out_bytes, hipMemcpyHostToDevice, st));
 #define UP(dst, vec) do { if (!(vec).empty()) HIP_TRY(hipMemcpyAsync((void*)(dst), (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, st)); } while (0)
     UP(w.J.v, H.v); UP(w.J.seed_ix, H.seed_ix); UP(w.J.proof_ix, H.proof_ix); UP(w.J.bl_plus, H.bl_plus); UP(w.J.bl_minus, H.bl_minus);
     UP(w.J.kind, H.kind); UP(w.J.proof_off, H.proof_off); UP(w.J.commit_off, H.commit_off);
     UP(w.J.ct_v, H.ct_v); UP(w.J.ct_seed_ix, H.ct_seed_ix); UP(w.J.ct_bl_ix, H.ct_bl_ix); UP(w.J.ct_off, H.ct_off);
 #undef UP
-    w.V.seeds = reinterpret_cast<const uint32_t*>(d_seeds); w.T.seeds = w.V.seeds; w.V.out = d_out;
-    rc = run_pipeline(w, M, C, st, sb);
-    if (rc == 0) {
-        HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
-    }
+    w.V.seeds = reinterpret_cast<const uint32_t*>(d_seeds); w.T.seeds = w.V.seeds; w.V.out = d_img;
+    if ((rc = run_pipeline(w, M, C, st, sb))) return rc;
+    HIP_TRY(hipEventRecord(sb.done, st)); sb.used = true;
+    return 0;
+}
+
+// out: host buffer already holding every framing byte; proofs and commitments are filled in by the device
+int run_host_jobs(const HostJobs& H, const uint8_t* seeds, size_t nseeds, uint8_t* out, size_t out_bytes, uint32_t lg = 6) {
+    if (H.v.empty() && H.ct_v.empty()) return 0;
+    hipStream_t st = dev().stream;
+    DevScope mem;
+    uint8_t *d_seeds = nullptr, *d_out = nullptr;
+    HIP_TRY(mem.alloc(&d_seeds, 32 * nseeds)); HIP_TRY(mem.alloc(&d_out, out_bytes));
+    HIP_TRY(hipMemcpyAsync(d_seeds, seeds, 32 * nseeds, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_out, out, out_bytes, hipMemcpyHostToDevice, st));
+    int rc = run_jobs_on(dev().sub[0], H, d_seeds, d_out, lg, st);
+    if (rc == 0) HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));          // nothing may still be using the per-call buffers when `mem` goes
     return rc;
 }
@@ -621,6 +712,64 @@ int fresh_seeds(std::vector<uint8_t>& buf, size_t n) {
     return 0;
 }
 
+uint64_t threshold_envelope_bytes(uint32_t lg) { return 10 + 8 + 4 + 4 + rp_bytes(lg) + 32 + 32; }      // 762 for n_bits = 64
+uint64_t consistency_envelope_bytes(uint32_t count) {
+    if (count == 0) return 0;
+    return 10 + 4 + 32ull * count + (uint64_t)(4 + RP_BYTES) * (count - 1) + 32ull * (count - 1) + 32;
+}
+// Framing of threshold proofs (threshold_proof.rs:12-32 -> bulletproofs.rs:309-366): validates every op, writes the envelope
+// and body framing of the valid ones into `img` (n records of `stride` bytes, zeroed by the caller) and appends one proof
+// job + one commitment task per valid op; seed index = op index.  Returns 1 if any op is invalid.
+int frame_threshold(uint64_t n, const uint64_t* values, const uint32_t* counts, const uint64_t* thresholds, uint32_t lg,
+                    uint8_t* img, uint64_t stride, uint32_t* out_len, int32_t* status, HostJobs& H) {
+    const uint32_t RP = rp_bytes(lg), n_bits = 1u << lg;
+    const uint64_t PB = threshold_envelope_bytes(lg);
+    const uint64_t max_diff = lg >= 6 ? ~0ull : (1ull << (1u << lg)) - 1;   // bulletproofs.rs:330-336
+    int any = 0; size_t pos = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        // validation.rs:30-47 / bulletproofs.rs:314-336
+        bool ok = counts[i] > 0; uint64_t sum = 0;
+        for (uint32_t k = 0; k < counts[i] && ok; k++) { const uint64_t x = values[pos + k]; if (sum + x < sum) ok = false; sum += x; }
+        pos += counts[i];
+        if (ok && sum < thresholds[i]) ok = false;
+        if (ok && sum - thresholds[i] > max_diff) ok = false;
+        status[i] = ok ? ZKP_HIP_OK : ZKP_HIP_INVALID_INPUT; out_len[i] = ok ? (uint32_t)PB : 0; any |= !ok;
+        if (!ok) continue;
+        uint8_t* o = img + i * stride; const uint64_t base = i * stride;
+        o[0] = 2; o[1] = 3; put_le_host(o + 2, 8 + 4 + 4 + RP + 32, 4); put_le_host(o + 6, 32, 4);
+        put_le_host(o + 10, thresholds[i], 8); put_le_host(o + 18, n_bits, 4); put_le_host(o + 22, RP, 4);
+        H.add_job(sum - thresholds[i], (uint32_t)i, 0, 0, -1, KIND_THRESHOLD, base + 26, base + 26 + RP);
+        H.add_commit(sum, (uint32_t)i, 0, base + 26 + RP + 32);
+    }
+    return any;
+}
+// Framing of consistency proofs (consistency_proof.rs:12-22 -> bulletproofs.rs:368-437): k commitment tasks and k - 1 proof
+// jobs per valid op.  The envelope's commitment field (SHA-256 of the commitment list) is filled in after the device run.
+int frame_consistency(uint64_t n, const uint64_t* data, const uint32_t* counts, uint8_t* img, uint64_t stride, uint32_t* out_len, int32_t* status, HostJobs& H) {
+    int any = 0; size_t pos = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint32_t k = counts[i]; const uint64_t* d = data + pos; pos += k;
+        bool ok = k > 0;                                            // validation.rs:75-88
+        for (uint32_t j = 1; j < k && ok; j++) if (d[j - 1] > d[j]) ok = false;
+        const uint64_t need = consistency_envelope_bytes(k);
+        if (ok && need > stride) ok = false;                        // (callers size the stride from the counts; never reached through the ABI)
+        status[i] = ok ? ZKP_HIP_OK : ZKP_HIP_INVALID_INPUT; out_len[i] = ok ? (uint32_t)need : 0; any |= !ok;
+        if (!ok) continue;
+        uint8_t* o = img + i * stride; const uint64_t base = i * stride;
+        const uint64_t body = need - 10 - 32;
+        o[0] = 2; o[1] = 6; put_le_host(o + 2, body, 4); put_le_host(o + 6, 32, 4);
+        put_le_host(o + 10, k, 4);
+        const uint64_t commits = base + 14, proofs = commits + 32ull * k, dcs = proofs + (uint64_t)(4 + RP_BYTES) * (k - 1);
+        for (uint32_t j = 0; j < k; j++) H.add_commit(d[j], (uint32_t)i, j, commits + 32ull * j);
+        for (uint32_t j = 1; j < k; j++) {
+            put_le_host(img + proofs + (uint64_t)(4 + RP_BYTES) * (j - 1), RP_BYTES, 4);
+            H.add_job(d[j] - d[j - 1], (uint32_t)i, j - 1, (int32_t)j, (int32_t)(j - 1), KIND_CONSISTENCY,
+                      proofs + (uint64_t)(4 + RP_BYTES) * (j - 1) + 4, dcs + 32ull * (j - 1));
+        }
+    }
+    return any;
+}
+
 }  // namespace
 
 #include "g16_impl.inc"
@@ -636,47 +785,123 @@ void zkp_hip_set_subbatches(uint32_t n) { g_subbatches = n; }
 void zkp_hip_set_msm_variant(uint32_t v) { if (v >= 100) g_fill = v / 100.0; }   // benchmarking knob: grid fill target x100 (single kernel variant remains)
 
 int zkp_hip_init(int device) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    return init_locked(device);
+    Device* d = nullptr;
+    {
+        Registry& R = registry();
+        std::lock_guard<std::mutex> lk(R.mu);
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            return fail(ZKP_HIP_E_RUNTIME, "zkp_hip_init: no HIP device available (this library has no CPU fallback)");
+        if (device < 0 || device >= ndev) return fail(ZKP_HIP_E_ARGUMENT, "zkp_hip_init: bad device index");
+        for (Device* s : R.shards) if (s->hip_dev == device) { d = s; break; }
+        if (!d) { d = new Device(); d->index = (int)R.shards.size(); d->hip_dev = device; R.shards.push_back(d); }
+        if (!R.hooked) { R.hooked = true; (void)atexit(zkp_hip_shutdown); }
+    }
+    Bind bind; int rc = bind.open(d);
+    drop_host_generator_tables();
+    return rc;
 }
 
-void zkp_hip_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g.ready) return;
-    (void)hipSetDevice(g.device);
-    (void)hipDeviceSynchronize();
-    g16_release_all();
-    bpv_release_all();
-    g_pool.release_all();
-    if (g_stark_const) { (void)hipFree(g_stark_const); g_stark_const = nullptr; }
-    for (auto& sb : g.sub) {
-        (void)hipFree(sb.ws); (void)hipStreamDestroy(sb.stream); (void)hipStreamDestroy(sb.side);
-        (void)hipEventDestroy(sb.start); (void)hipEventDestroy(sb.done); (void)hipEventDestroy(sb.side_go); (void)hipEventDestroy(sb.side_done);
+int zkp_hip_init_devices(uint32_t count, const int* devices) {
+    if (count == 0 || count > 64 || !devices) return fail(ZKP_HIP_E_ARGUMENT, "zkp_hip_init_devices: 1..64 shards");
+    std::vector<Device*> mine;
+    {
+        Registry& R = registry();
+        std::lock_guard<std::mutex> lk(R.mu);
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            return fail(ZKP_HIP_E_RUNTIME, "zkp_hip_init: no HIP device available (this library has no CPU fallback)");
+        for (uint32_t k = 0; k < count; k++) if (devices[k] < 0 || devices[k] >= ndev) return fail(ZKP_HIP_E_ARGUMENT, "zkp_hip_init_devices: bad device index");
+        if (!R.shards.empty()) {                       // idempotent for the same assignment; anything else needs a shutdown first
+            bool same = R.shards.size() == count;
+            for (uint32_t k = 0; same && k < count; k++) same = R.shards[k]->hip_dev == devices[k];
+            if (!same) return fail(ZKP_HIP_E_ARGUMENT, "zkp_hip_init_devices: shards are already registered differently (zkp_hip_shutdown first)");
+        } else {
+            for (uint32_t k = 0; k < count; k++) { Device* d = new Device(); d->index = (int)k; d->hip_dev = devices[k]; R.shards.push_back(d); }
+        }
+        mine = R.shards;
+        if (!R.hooked) { R.hooked = true; (void)atexit(zkp_hip_shutdown); }
     }
-    (void)hipFree(g.d_table);
-    free_set(g.p2); free_set(g.ct);
-    for (auto& F : g.fam) { free_set(F.p1); for (auto& d : F.rd) free_set(d); }
-    for (auto& e : g.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    (void)hipStreamDestroy(g.stream);
-    g = Ctx();
-}
-
-void zkp_hip_profile_enable(int on) { std::lock_guard<std::mutex> lk(g_mu); g.profiling = on != 0; }
-
-int zkp_hip_profile_read(double* msm_ms, uint64_t* msm_launches, uint64_t* msm_point_adds, int reset) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (!g.ready) return fail(ZKP_HIP_E_ARGUMENT, "not initialised");
-    HIP_TRY(hipSetDevice(g.device));
-    HIP_TRY(hipDeviceSynchronize());
-    for (size_t i = 0; i < g.ev_used; i++) {
-        float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, g.ev_pool[i].first, g.ev_pool[i].second)); g.msm_ms += ms;
-    }
-    g.ev_used = 0;
-    if (msm_ms) *msm_ms = g.msm_ms;
-    if (msm_launches) *msm_launches = g.msm_launches;
-    if (msm_point_adds) *msm_point_adds = g.msm_adds;
-    if (reset) { g.msm_ms = 0; g.msm_launches = 0; g.msm_adds = 0; }
+    (void)host_generator_tables();                     // once, before the per-shard workers need it
+    std::vector<int> rcs(count, 0); std::vector<std::string> errs(count);
+    std::vector<std::thread> th;
+    for (uint32_t k = 0; k < count; k++) th.emplace_back([&, k]() { Bind bind; rcs[k] = bind.open(mine[k]); if (rcs[k]) errs[k] = t_err; });
+    for (auto& t : th) t.join();
+    drop_host_generator_tables();
+    for (uint32_t k = 0; k < count; k++) if (rcs[k]) return fail(rcs[k], errs[k]);
     return 0;
+}
+
+int zkp_hip_device_count(void) { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); return (int)R.shards.size(); }
+
+int zkp_hip_use_device(int shard) {
+    Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu);
+    if (shard < 0 || (shard > 0 && shard >= (int)R.shards.size())) return fail(ZKP_HIP_E_ARGUMENT, "zkp_hip_use_device: no such shard");
+    t_sel = shard;
+    return 0;
+}
+
+// Releases every device resource of every shard and forgets the shard registration.  Also the library's atexit hook: it
+// runs while the HIP runtime is still alive, so nothing of ours (streams, events, allocations, code objects in use) is
+// left for the runtime's own exit-time teardown to trip over.  The Device objects themselves are never freed.
+void zkp_hip_shutdown(void) {
+    std::vector<Device*> shards;
+    { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); shards.swap(R.shards); R.host_table.reset(); }
+    t_sel = 0;
+    for (Device* d : shards) {
+        std::lock_guard<std::mutex> lk(d->mu);
+        if (!d->ready) continue;
+        Device* prev = t_dev; t_dev = d;
+        (void)hipSetDevice(d->hip_dev);
+        (void)hipDeviceSynchronize();
+        batch_release_all();
+        g16_release_all();
+        bpv_release_all();
+        stark_release_all();
+        d->pool.release_all();
+        for (auto& sb : d->sub) {
+            (void)hipFree(sb.ws); (void)hipStreamDestroy(sb.stream); (void)hipStreamDestroy(sb.side);
+            (void)hipEventDestroy(sb.start); (void)hipEventDestroy(sb.done); (void)hipEventDestroy(sb.side_go); (void)hipEventDestroy(sb.side_done);
+        }
+        d->sub.clear();
+        (void)hipFree(d->d_table); d->d_table = nullptr;
+        free_set(d->p2); free_set(d->ct);
+        for (auto& F : d->fam) { free_set(F.p1); for (auto& s : F.rd) free_set(s); F.ready = false; }
+        for (auto& K : d->prof) { for (auto& e : K.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } K = Device::KProf(); }
+        (void)hipStreamDestroy(d->stream); d->stream = nullptr;
+        d->ready = false; d->profiling = false; d->max_chunks = 0; d->next_slot = 0; d->generation++;
+        t_dev = prev;
+    }
+}
+
+void zkp_hip_profile_enable(int on) {
+    Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu);
+    for (Device* d : R.shards) { std::lock_guard<std::mutex> dl(d->mu); d->profiling = on != 0; }
+}
+
+// accumulated over all shards
+int zkp_hip_profile_read_kernel(int which, double* ms, uint64_t* launches, uint64_t* point_adds, int reset) {
+    if (which < 0 || which > 2) return fail(ZKP_HIP_E_ARGUMENT, "unknown kernel id");
+    std::vector<Device*> shards;
+    { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); shards = R.shards; }
+    double tms = 0; uint64_t tl = 0, ta = 0;
+    for (Device* d : shards) {
+        Bind bind; int rc = bind.open(d);
+        if (rc) return rc;
+        HIP_TRY(hipDeviceSynchronize());
+        Device::KProf& K = d->prof[which];
+        for (size_t i = 0; i < K.ev_used; i++) { float t = 0; HIP_TRY(hipEventElapsedTime(&t, K.ev_pool[i].first, K.ev_pool[i].second)); K.ms += t; }
+        K.ev_used = 0;
+        tms += K.ms; tl += K.launches; ta += K.adds;
+        if (reset) { K.ms = 0; K.launches = 0; K.adds = 0; }
+    }
+    if (ms) *ms = tms;
+    if (launches) *launches = tl;
+    if (point_adds) *point_adds = ta;
+    return 0;
+}
+int zkp_hip_profile_read(double* msm_ms, uint64_t* msm_launches, uint64_t* msm_point_adds, int reset) {
+    return zkp_hip_profile_read_kernel(0, msm_ms, msm_launches, msm_point_adds, reset);
 }
 
 int zkp_hip_prove_range_batch_device(uint64_t n, const uint64_t* d_value, const uint64_t* d_min, const uint64_t* d_max, uint32_t n_bits,
@@ -685,11 +910,9 @@ int zkp_hip_prove_range_batch_device(uint64_t n, const uint64_t* d_value, const 
     uint32_t lg;
     if (!bits_to_lg(n_bits, &lg)) return fail(ZKP_HIP_E_UNSUPPORTED, "n_bits must be 8, 16, 32 or 64");
     if (!d_seeds) return fail(ZKP_HIP_E_ARGUMENT, "device entry point needs seeds");
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = init_locked(g.ready ? g.device : 0);
+    Bind bind; int rc = bind.open();
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(g.device));
-    hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+    hipStream_t st = stream ? (hipStream_t)stream : dev().stream;
     rc = prove_range_device_locked(n, d_value, d_min, d_max, lg, d_seeds, d_out, stride, d_out_len, d_status, st, any_failed);
     if (rc) return rc;
     return (any_failed && *any_failed) ? 1 : 0;
@@ -704,11 +927,9 @@ int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t*
     if (stride < range_envelope_bytes(lg)) return fail(ZKP_HIP_E_ARGUMENT, "stride is smaller than the proof (1478 bytes for n_bits = 64)");
     std::vector<uint8_t> fresh;
     if (!seeds) { int rc0 = fresh_seeds(fresh, n); if (rc0) return rc0; seeds = fresh.data(); }   // bulletproofs.rs:82-87
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = init_locked(g.ready ? g.device : 0);
+    Bind bind; int rc = bind.open();
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(g.device));
-    hipStream_t st = g.stream;
+    hipStream_t st = dev().stream;
     DevScope mem;
     uint64_t *d_in = nullptr; uint8_t *d_seeds = nullptr, *d_out = nullptr; uint32_t* d_len = nullptr; int32_t* d_status = nullptr;
     HIP_TRY(mem.alloc(&d_in, 24 * n)); HIP_TRY(mem.alloc(&d_seeds, 32 * n)); HIP_TRY(mem.alloc(&d_out, stride * n));
@@ -733,12 +954,8 @@ int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t*
 }
 
 uint64_t zkp_hip_range_proof_bytes(uint32_t n_bits) { uint32_t lg; return bits_to_lg(n_bits, &lg) ? range_envelope_bytes(lg) : 0; }
-uint64_t zkp_hip_threshold_proof_bytes(uint32_t n_bits) { uint32_t lg; return bits_to_lg(n_bits, &lg) ? 10 + 8 + 4 + 4 + rp_bytes(lg) + 32 + 32 : 0; }
-
-uint64_t zkp_hip_consistency_proof_bytes(uint32_t count) {
-    if (count == 0) return 0;
-    return 10 + 4 + 32ull * count + (uint64_t)(4 + RP_BYTES) * (count - 1) + 32ull * (count - 1) + 32;
-}
+uint64_t zkp_hip_threshold_proof_bytes(uint32_t n_bits) { uint32_t lg; return bits_to_lg(n_bits, &lg) ? threshold_envelope_bytes(lg) : 0; }
+uint64_t zkp_hip_consistency_proof_bytes(uint32_t count) { return consistency_envelope_bytes(count); }
 
 int zkp_hip_prove_threshold_batch(uint64_t n, const uint64_t* values, const uint32_t* counts, const uint64_t* thresholds, uint32_t n_bits,
                                   const uint8_t* seeds, uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
@@ -746,33 +963,14 @@ int zkp_hip_prove_threshold_batch(uint64_t n, const uint64_t* values, const uint
     if (!bits_to_lg(n_bits, &lg)) return fail(ZKP_HIP_E_UNSUPPORTED, "n_bits must be 8, 16, 32 or 64");
     if (n == 0) return 0;
     if (!values || !counts || !thresholds || !out || !out_len || !status) return fail(ZKP_HIP_E_ARGUMENT, "null pointer argument");
-    const uint32_t RP = rp_bytes(lg);
-    const uint64_t PB = 10 + 8 + 4 + 4 + RP + 32 + 32;                      // 762 for n_bits = 64
-    const uint64_t max_diff = lg >= 6 ? ~0ull : (1ull << (1u << lg)) - 1;   // bulletproofs.rs:330-336
-    if (stride < PB) return fail(ZKP_HIP_E_ARGUMENT, "stride is smaller than the proof (762 bytes for n_bits = 64)");
+    if (stride < threshold_envelope_bytes(lg)) return fail(ZKP_HIP_E_ARGUMENT, "stride is smaller than the proof (762 bytes for n_bits = 64)");
     std::vector<uint8_t> fresh;
     if (!seeds) { int rc = fresh_seeds(fresh, n); if (rc) return rc; seeds = fresh.data(); }
-    HostJobs H; int any = 0; size_t pos = 0;
+    HostJobs H;
     memset(out, 0, stride * n);
-    for (uint64_t i = 0; i < n; i++) {
-        // validation.rs:30-47 / bulletproofs.rs:314-336
-        bool ok = counts[i] > 0; uint64_t sum = 0;
-        for (uint32_t k = 0; k < counts[i] && ok; k++) { const uint64_t x = values[pos + k]; if (sum + x < sum) ok = false; sum += x; }
-        pos += counts[i];
-        if (ok && sum < thresholds[i]) ok = false;
-        if (ok && sum - thresholds[i] > max_diff) ok = false;
-        status[i] = ok ? ZKP_HIP_OK : ZKP_HIP_INVALID_INPUT; out_len[i] = ok ? (uint32_t)PB : 0; any |= !ok;
-        if (!ok) continue;
-        uint8_t* o = out + i * stride; const uint64_t base = i * stride;
-        o[0] = 2; o[1] = 3; put_le_host(o + 2, 8 + 4 + 4 + RP + 32, 4); put_le_host(o + 6, 32, 4);
-        put_le_host(o + 10, thresholds[i], 8); put_le_host(o + 18, n_bits, 4); put_le_host(o + 22, RP, 4);
-        H.add_job(sum - thresholds[i], (uint32_t)i, 0, 0, -1, KIND_THRESHOLD, base + 26, base + 26 + RP);
-        H.add_commit(sum, (uint32_t)i, 0, base + 26 + RP + 32);
-    }
-    std::lock_guard<std::mutex> lk(g_mu);
-    int rc = init_locked(g.ready ? g.device : 0);
+    const int any = frame_threshold(n, values, counts, thresholds, lg, out, stride, out_len, status, H);
+    Bind bind; int rc = bind.open();
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(g.device));
     if ((rc = run_host_jobs(H, seeds, n, out, stride * n, lg))) return rc;
     return any;
 }
@@ -783,34 +981,18 @@ int zkp_hip_prove_consistency_batch(uint64_t n, const uint64_t* data, const uint
     if (!data || !counts || !out || !out_len || !status) return fail(ZKP_HIP_E_ARGUMENT, "null pointer argument");
     std::vector<uint8_t> fresh;
     if (!seeds) { int rc = fresh_seeds(fresh, n); if (rc) return rc; seeds = fresh.data(); }
-    HostJobs H; int any = 0; size_t pos = 0;
-    memset(out, 0, stride * n);
-    std::vector<size_t> starts(n);
+    size_t pos = 0;
     for (uint64_t i = 0; i < n; i++) {
-        const uint32_t k = counts[i]; const uint64_t* d = data + pos; starts[i] = pos; pos += k;
-        bool ok = k > 0;                                            // validation.rs:75-88
-        for (uint32_t j = 1; j < k && ok; j++) if (d[j - 1] > d[j]) ok = false;
-        const uint64_t need = zkp_hip_consistency_proof_bytes(k);
-        if (ok && need > stride) return fail(ZKP_HIP_E_ARGUMENT, "stride too small for a consistency proof (see zkp_hip_consistency_proof_bytes)");
-        status[i] = ok ? ZKP_HIP_OK : ZKP_HIP_INVALID_INPUT; out_len[i] = ok ? (uint32_t)need : 0; any |= !ok;
-        if (!ok) continue;
-        uint8_t* o = out + i * stride; const uint64_t base = i * stride;
-        const uint64_t body = need - 10 - 32;
-        o[0] = 2; o[1] = 6; put_le_host(o + 2, body, 4); put_le_host(o + 6, 32, 4);
-        put_le_host(o + 10, k, 4);
-        const uint64_t commits = base + 14, proofs = commits + 32ull * k, dcs = proofs + (uint64_t)(4 + RP_BYTES) * (k - 1);
-        for (uint32_t j = 0; j < k; j++) H.add_commit(d[j], (uint32_t)i, j, commits + 32ull * j);
-        for (uint32_t j = 1; j < k; j++) {
-            put_le_host(out + proofs + (uint64_t)(4 + RP_BYTES) * (j - 1), RP_BYTES, 4);
-            H.add_job(d[j] - d[j - 1], (uint32_t)i, j - 1, (int32_t)j, (int32_t)(j - 1), KIND_CONSISTENCY,
-                      proofs + (uint64_t)(4 + RP_BYTES) * (j - 1) + 4, dcs + 32ull * (j - 1));
-        }
+        bool ok = counts[i] > 0; for (uint32_t j = 1; j < counts[i] && ok; j++) if (data[pos + j - 1] > data[pos + j]) ok = false;
+        if (ok && zkp_hip_consistency_proof_bytes(counts[i]) > stride) return fail(ZKP_HIP_E_ARGUMENT, "stride too small for a consistency proof (see zkp_hip_consistency_proof_bytes)");
+        pos += counts[i];
     }
+    HostJobs H;
+    memset(out, 0, stride * n);
+    const int any = frame_consistency(n, data, counts, out, stride, out_len, status, H);
     {
-        std::lock_guard<std::mutex> lk(g_mu);
-        int rc = init_locked(g.ready ? g.device : 0);
+        Bind bind; int rc = bind.open();
         if (rc) return rc;
-        HIP_TRY(hipSetDevice(g.device));
         if ((rc = run_host_jobs(H, seeds, n, out, stride * n))) return rc;
     }
     for (uint64_t i = 0; i < n; i++) {          // commitment field = SHA-256 of the commitment list (bulletproofs.rs:430-436)

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #include <map>
+#include <string>
 __global__ void probe(uint32_t* out, int spin) {
     uint32_t xcc, hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -25,7 +26,11 @@ static void run(const char* name, hipStream_t st, int nblocks) {
     printf("\n");
     hipFree(d);
 }
+// `--leak`: leave one CU-masked stream alive at exit (no hipStreamDestroy).  Round 1 saw an exit-time SIGSEGV inside
+// __cxa_finalize under rocprofv3 in exactly the two runs whose builds created such streams and never destroyed them;
+// this switch reproduces that condition in isolation ("exit-time teardown").
 int main(int argc, char** argv) {
+    const bool leak = argc > 1 && std::string(argv[1]) == "--leak";
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     printf("CUs %d\n", p.multiProcessorCount);
     hipStream_t s0; hipStreamCreate(&s0);
@@ -40,6 +45,7 @@ int main(int argc, char** argv) {
         hipStream_t s; hipError_t e = hipExtStreamCreateWithCUMask(&s, 8, mask);
         if (e != hipSuccess) { printf("%s: create failed: %s\n", name, hipGetErrorString(e)); continue; }
         run(name, s, 4096);
+        if (leak && variant == 3) { printf("leaving the CU-masked stream of variant 3 alive at exit\n"); continue; }
         hipStreamDestroy(s);
     }
     return 0;
