@@ -39,20 +39,28 @@ static void m_sub(const modctx* M, fp* r, const fp* a, const fp* b) {
     if (sub4(t, a->v, b->v)) add4(t, t, M->p);
     memcpy(r->v, t, 32);
 }
-static void m_mul(const modctx* M, fp* r, const fp* a, const fp* b) {
-    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+/* Montgomery product, CIOS without the extra carry word (valid because the top bit of both BN254 moduli is clear); the
+ * modulus and -p^-1 mod 2^64 are compile-time constants at every call site so the loops unroll into straight-line code */
+#define INV_Q 0x87d20782e4866389ull
+#define INV_R 0xc2e1f593efffffffull
+static inline __attribute__((always_inline)) void mont_mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4], const uint64_t p[4], const uint64_t inv) {
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
     for (int i = 0; i < 4; i++) {
-        uint64_t carry = 0;
-        for (int j = 0; j < 4; j++) { u128 s = (u128)a->v[j] * b->v[i] + t[j] + carry; t[j] = (uint64_t)s; carry = (uint64_t)(s >> 64); }
-        u128 s = (u128)t[4] + carry; t[4] = (uint64_t)s; t[5] = (uint64_t)(s >> 64);
-        const uint64_t m = t[0] * M->inv;
-        s = (u128)m * M->p[0] + t[0]; carry = (uint64_t)(s >> 64);
-        for (int j = 1; j < 4; j++) { s = (u128)m * M->p[j] + t[j] + carry; t[j - 1] = (uint64_t)s; carry = (uint64_t)(s >> 64); }
-        s = (u128)t[4] + carry; t[3] = (uint64_t)s; t[4] = t[5] + (uint64_t)(s >> 64); t[5] = 0;
+        u128 A = (u128)a[0] * b[i] + t0;
+        const uint64_t m = (uint64_t)A * inv;
+        u128 C = (u128)m * p[0] + (uint64_t)A;
+        A = (u128)a[1] * b[i] + t1 + (uint64_t)(A >> 64); C = (u128)m * p[1] + (uint64_t)A + (uint64_t)(C >> 64); t0 = (uint64_t)C;
+        A = (u128)a[2] * b[i] + t2 + (uint64_t)(A >> 64); C = (u128)m * p[2] + (uint64_t)A + (uint64_t)(C >> 64); t1 = (uint64_t)C;
+        A = (u128)a[3] * b[i] + t3 + (uint64_t)(A >> 64); C = (u128)m * p[3] + (uint64_t)A + (uint64_t)(C >> 64); t2 = (uint64_t)C;
+        t3 = (uint64_t)(C >> 64) + (uint64_t)(A >> 64);
     }
-    if (t[4] || geq(t, M->p)) sub4(t, t, M->p);
-    memcpy(r->v, t, 32);
+    uint64_t t[4] = {t0, t1, t2, t3}, u[4];
+    const uint64_t borrow = sub4(u, t, p);
+    if (!borrow) memcpy(r, u, 32); else memcpy(r, t, 32);
 }
+static void mq_mul(fp* r, const fp* a, const fp* b) { mont_mul(r->v, a->v, b->v, P_Q, INV_Q); }
+static void mr_mul(fp* r, const fp* a, const fp* b) { mont_mul(r->v, a->v, b->v, P_R, INV_R); }
+static void m_mul(const modctx* M, fp* r, const fp* a, const fp* b) { if (M == &MQ) mq_mul(r, a, b); else mr_mul(r, a, b); }
 static void m_pow(const modctx* M, fp* r, const fp* a, const uint64_t e[4]) {
     fp acc = M->one, base = *a;
     for (int i = 0; i < 256; i++) {
@@ -73,6 +81,7 @@ static void ctx_init(modctx* M, const uint64_t p[4]) {
     uint64_t x = 1;                                           /* -p^-1 mod 2^64 by Newton iteration */
     for (int i = 0; i < 6; i++) x *= 2 - p[0] * x;
     M->inv = (uint64_t)0 - x;
+    if (M->inv != (p == P_Q ? INV_Q : INV_R)) abort();       /* the hard-coded constants above are -p^-1 mod 2^64 */
     fp t = {{1, 0, 0, 0}};                                    /* 2^512 mod p by 512 modular doublings */
     fp one_m;
     for (int i = 0; i < 512; i++) {
@@ -96,7 +105,7 @@ void bn254_init(void) {
 void fq_add(fp* r, const fp* a, const fp* b) { m_add(&MQ, r, a, b); }
 void fq_sub(fp* r, const fp* a, const fp* b) { m_sub(&MQ, r, a, b); }
 void fq_neg(fp* r, const fp* a) { fp z; memset(&z, 0, sizeof z); m_sub(&MQ, r, &z, a); }
-void fq_mul(fp* r, const fp* a, const fp* b) { m_mul(&MQ, r, a, b); }
+void fq_mul(fp* r, const fp* a, const fp* b) { mq_mul(r, a, b); }
 void fq_inv(fp* r, const fp* a) { m_inv(&MQ, r, a); }
 int fq_is_zero(const fp* a) { return (a->v[0] | a->v[1] | a->v[2] | a->v[3]) == 0; }
 int fq_from_bytes(fp* r, const uint8_t b[32]) {
@@ -117,7 +126,7 @@ int fq_lex_larger(const fp* a) {
 void fr_add(fp* r, const fp* a, const fp* b) { m_add(&MR, r, a, b); }
 void fr_sub(fp* r, const fp* a, const fp* b) { m_sub(&MR, r, a, b); }
 void fr_neg(fp* r, const fp* a) { m_sub(&MR, r, &FR_ZERO, a); }
-void fr_mul(fp* r, const fp* a, const fp* b) { m_mul(&MR, r, a, b); }
+void fr_mul(fp* r, const fp* a, const fp* b) { mr_mul(r, a, b); }
 void fr_inv(fp* r, const fp* a) { m_inv(&MR, r, a); }
 void fr_pow_u64(fp* r, const fp* a, uint64_t e) { const uint64_t ee[4] = {e, 0, 0, 0}; m_pow(&MR, r, a, ee); }
 void fr_from_u64(fp* r, uint64_t x) { const uint64_t w[4] = {x, 0, 0, 0}; m_from_raw(&MR, r, w); }
@@ -220,44 +229,4 @@ void g2_serialize(uint8_t b[128], const g2a* p) {
     /* ark_ff QuadExtField ordering: c1 first, then c0 */
     const int larger = fq_is_zero(&p->y.c1) ? fq_lex_larger(&p->y.c0) : fq_lex_larger(&p->y.c1);
     if (larger) b[127] |= 0x80;
-}
-
-/* ---------------------------------------------------------------- SHA-256 (FIPS 180-4) */
-static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
-static const uint32_t SHA_K[64] = {
-    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
-    0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
-    0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
-    0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
-    0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
-    0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-static void sha_block(uint32_t h[8], const uint8_t blk[64]) {
-    uint32_t w[64];
-    for (int i = 0; i < 16; i++) w[i] = ((uint32_t)blk[4 * i] << 24) | ((uint32_t)blk[4 * i + 1] << 16) | ((uint32_t)blk[4 * i + 2] << 8) | blk[4 * i + 3];
-    for (int i = 16; i < 64; i++) {
-        const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
-        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
-    }
-    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-    for (int i = 0; i < 64; i++) {
-        const uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[i] + w[i];
-        const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
-        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-    }
-    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
-}
-void oracle_sha256(uint8_t out[32], const uint8_t* in, size_t len) {
-    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
-    size_t off = 0;
-    for (; off + 64 <= len; off += 64) sha_block(h, in + off);
-    uint8_t blk[128]; memset(blk, 0, sizeof blk);
-    const size_t rem = len - off;
-    memcpy(blk, in + off, rem);
-    blk[rem] = 0x80;
-    const size_t tot = rem >= 56 ? 128 : 64;
-    const uint64_t bits = (uint64_t)len * 8;
-    for (int i = 0; i < 8; i++) blk[tot - 1 - i] = (uint8_t)(bits >> (8 * i));
-    sha_block(h, blk);
-    if (tot == 128) sha_block(h, blk + 64);
-    for (int k = 0; k < 8; k++) { out[4 * k] = (uint8_t)(h[k] >> 24); out[4 * k + 1] = (uint8_t)(h[k] >> 16); out[4 * k + 2] = (uint8_t)(h[k] >> 8); out[4 * k + 3] = (uint8_t)h[k]; }
 }

@@ -69,7 +69,4 @@ void g2j_to_affine(g2a* r, const g2j* p);
 int g2_parse(g2a* r, const uint8_t b[128]);
 void g2_serialize(uint8_t b[128], const g2a* p);
 void g2_msm(g2j* r, size_t n, const fp* scalars_fr, const g2a* bases);
-
-/* SHA-256 (mimc constants, snark.rs:186-199; improvement commitment, utils/commitment.rs:38-50) */
-void oracle_sha256(uint8_t out[32], const uint8_t* in, size_t len);
 #endif

@@ -45,6 +45,22 @@ int zkp_oracle_prove_range_batch(uint64_t n, const uint64_t* value, const uint64
 int zkp_oracle_verify_range_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, const uint32_t* len, const uint64_t* min,
                                   const uint64_t* max, uint8_t* ok, int nthreads);
 
+/* ---- SNARK path (groth16.c; PARITY UNPINNED, pinned to oracle/py/groth16.py): kind 0 = equality_mimc, 1 = membership_mimc;
+ * pk = ark-serialize uncompressed ProvingKey<Bn254>, the reference's own {prefix}_pk.bin format (snark.rs:31-38) */
+int zkp_oracle_g16_load_key(int kind, const uint8_t* pk, uint64_t len);
+int zkp_oracle_snark_commit_value(uint64_t value, uint8_t out[32]);
+int zkp_oracle_prove_equality(uint64_t val1, uint64_t val2, const uint8_t seed[32], uint8_t* out, uint32_t cap, uint32_t* out_len);
+int zkp_oracle_prove_membership(uint64_t value, const uint64_t* set, uint32_t count, const uint8_t seed[32], uint8_t* out, uint32_t cap, uint32_t* out_len);
+/* ---- STARK path (stark.c; PARITY UNPINNED, pinned to oracle/py/stark.py): deterministic, cap >= 3527 */
+int zkp_oracle_prove_improvement(uint64_t old_value, uint64_t new_value, uint8_t* out, uint32_t cap, uint32_t* out_len);
+
+/* advanced::process_batch (/root/reference/src/advanced/batch.rs:110-140,262-283): one OpenMP task per op, like the rayon
+ * par_iter; same op record and output convention as zkp_hip_process_batch (proof i at out[out_off[i] .. out_off[i+1])).
+ * Returns 1 if any op failed, ZKP_ORACLE_BUFFER_TOO_SMALL if out_cap is too small (out_off[n] = needed). */
+typedef struct zkp_oracle_op { uint32_t kind, count; uint64_t a, b, c, list_off; } zkp_oracle_op;
+int zkp_oracle_process_batch(uint64_t n, const zkp_oracle_op* ops, const uint64_t* lists, const uint8_t* seeds,
+                             uint8_t* out, uint64_t out_cap, uint64_t* out_off, int32_t* status, int nthreads);
+
 /* tape + generator access for kernel-level parity tests */
 void zkp_oracle_tape_draw64(const uint8_t seed[32], uint32_t proof_idx, uint32_t slot, uint8_t out[64]);
 void zkp_oracle_generator(uint32_t index, uint8_t enc[32]); /* 0 = B, 1 = B_blinding, 2+i = G_i, 66+i = H_i (party 0) */
