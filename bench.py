@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
-"""Headline benchmark: process_batch of 4096 prove_range(v, 0, 2^32) per GPU (BASELINE.json configs[1]).
+"""Headline benchmark: process_batch of a 4096-op MIXED batch per GPU (BASELINE.json's metric).
 
-One "step" = one pass of the HIP range prover over one batch of 4096 synthetic ops whose inputs (values,
-bounds, per-proof seeds) are already resident in HBM; proofs are left in HBM.  Multi-GPU = one process per
-GPU, each proving its own 4096-op batch (independent ops, no data-path collective; weak scaling).
+Workload (SURVEY.md 8d, C5's mix at the metric's 4096-op size): op i is prove_range(v, 0, 2^32) / prove_equality(a, a) /
+prove_membership(value, 16-element set) / prove_improvement(old, new) for i mod 4 = 0 / 1 / 2 / 3, seed 5 (+ rank), per-proof
+seeds SHA-256(seed || i).  One "step" = zkp_hip_batch_prove on that batch: the whole scheduler of zkp_hip_process_batch
+(batch.rs:110-140 replacement) with the batch already staged in HBM and the packed proofs + offsets left in HBM.  The
+same batch through zkp_hip_process_batch with host buffers in and out (staging, H2D, D2H included) is reported beside it as
+`host_buffers` -- it is never `value`.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel (fixed-base MSM) against the HBM roof, as the contract asks, plus
-  roofline_valu the same kernel against the VALU integer roof that actually binds it
-  cpu_baseline  oracle/c (a scalar C port of upstream's algorithm, OpenMP over proofs) on a bounded sample.
+Multi-GPU: one process per GPU (the driver launches `python -m torch.distributed.run ... bench.py --gpus N`; a bare
+`python bench.py --gpus N` launches those children itself before anything touches the GPU).  Every rank proves its own
+4096-op batch (weak scaling: the ops are independent, there is no data-path exchange inside the proving) and the packed
+proofs of all ranks are gathered to every rank with one RCCL all_gather inside the timed region, which is what a node-level
+process_batch has to hand back.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+  roofline       the dominant kernel of the mixed batch, k_msm_dma<G1Msm> (Groth16 key-point MSMs), against the HBM roof
+  roofline_valu  the same kernel against the VALU integer roof that actually binds it
+  cpu_baseline   oracle/c's process_batch port (OpenMP over ops, like rayon) on a bounded sample of the same ops.
 """
 import argparse
 import ctypes
-import hashlib
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -23,56 +33,59 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BATCH = 4096
-PROOF_BYTES = 1478
-ALGO_BYTES_PER_PROOF = 24 + 32 + 1478   # params + seed in, proof out
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md
-FE_MUL_PEAK_G = 257.0                    # measured: tools/fe_microbench.hip variant B on MI355X (G field-mul/s)
-FE_MUL_PER_POINT_ADD = 7
+FQ_MUL_PEAK_G = 128.5                    # G BN254-Fq products/s: 25.7 T v_mad_u64_u32/s measured (profiles/r02_fe_microbench.json) / 200 per product
+FQ_MUL_PER_G1_MADD = 11                  # 7M + 4S (madd-2007-bl)
+FE_MUL_PEAK_G = 257.0                    # G GF(2^255-19) products/s (100 v_mad_u64_u32 each), same microbenchmark
+ALGO_BYTES = {"range": 24 + 32 + 1478, "equality": 16 + 32 + 298, "membership16": 8 + 128 + 32 + 430}
 
 
-def make_workload(n, seed):
-    """C2 of BASELINE.md: value ~ U[0, 2^32], min = 0, max = 2^32; per-proof seed = SHA-256(seed || i)."""
-    import numpy as np
-    rng = np.random.default_rng(seed)
-    v = rng.integers(0, 2**32, n, dtype=np.uint64, endpoint=True)
-    mn = np.zeros(n, dtype=np.uint64)
-    mx = np.full(n, 2**32, dtype=np.uint64)
-    seeds = np.frombuffer(b"".join(hashlib.sha256(seed.to_bytes(8, "little") + i.to_bytes(8, "little")).digest() for i in range(n)), dtype=np.uint8).copy()
-    return v, mn, mx, seeds
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _relaunch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks as children of a process that has not touched the GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
 
 
 def cpu_baseline(sample, threads):
+    """The mixed batch on the host cores: oracle/c's port of process_batch (one OpenMP task per op), on the first `sample`
+    ops of the same workload.  kind = "port": C restatements of upstream's algorithms, not the Rust crates themselves."""
     import numpy as np
-    path = os.path.join(ROOT, "oracle", "_build", "libzkp_oracle.so")
-    orc = ctypes.CDLL(path)
+    from libzkp_amd import workloads as wl
+    orc = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libzkp_oracle.so"))
     orc.zkp_oracle_init()
-    v, mn, mx, seeds = make_workload(sample, 1)
-    out = np.zeros((sample, PROOF_BYTES), dtype=np.uint8)
-    lens = np.zeros(sample, dtype=np.uint32)
-    st = np.zeros(sample, dtype=np.int32)
     P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     u64 = ctypes.c_uint64
-    # warm-up (thread pool, page faults)
-    orc.zkp_oracle_prove_range_batch(u64(min(sample, threads)), P(v), P(mn), P(mx), 64, P(seeds), P(out), u64(PROOF_BYTES), P(lens), P(st), threads)
+    for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")):
+        pk = open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
+        assert orc.zkp_oracle_g16_load_key(kind, pk, u64(len(pk))) == 0
+    ops, lists, seeds = wl.mixed_ops(BATCH, 5)
+    ops, seeds = ops[:sample].copy(), seeds[:32 * sample].copy()
+    cap = wl.max_output_bytes(ops)
+    out = np.zeros(cap, dtype=np.uint8); off = np.zeros(sample + 1, dtype=np.uint64); st = np.zeros(sample, dtype=np.int32)
+    warm = min(sample, 4 * threads)
+    orc.zkp_oracle_process_batch(u64(warm), P(ops), P(lists), P(seeds), P(out), u64(cap), P(off), P(st), threads)      # thread pool, page faults
     t0 = time.perf_counter()
-    rc = orc.zkp_oracle_prove_range_batch(u64(sample), P(v), P(mn), P(mx), 64, P(seeds), P(out), u64(PROOF_BYTES), P(lens), P(st), threads)
+    rc = orc.zkp_oracle_process_batch(u64(sample), P(ops), P(lists), P(seeds), P(out), u64(cap), P(off), P(st), threads)
     dt = time.perf_counter() - t0
     assert rc == 0
-    # BASELINE.md B2 / configs[0]: the reference's own harness shape, benchmark_proof_generation("range", 100)
-    # (advanced/mod.rs:83-172: 100 x prove_range(50, 0, 100), one thread), next to the README's "~5 ms" figure
+    # BASELINE configs[0]: the reference's own harness shape, benchmark_proof_generation("range", 100) = 100 x prove_range(50, 0, 100), one thread
     k = 100
     v1, mn1, mx1 = np.full(k, 50, dtype=np.uint64), np.zeros(k, dtype=np.uint64), np.full(k, 100, dtype=np.uint64)
-    sd1 = make_workload(k, 7)[3]
-    out1, len1, st1 = np.zeros((k, PROOF_BYTES), dtype=np.uint8), np.zeros(k, dtype=np.uint32), np.zeros(k, dtype=np.int32)
+    sd1 = wl.op_seeds(7, k)
+    out1, len1, st1 = np.zeros((k, 1478), dtype=np.uint8), np.zeros(k, dtype=np.uint32), np.zeros(k, dtype=np.int32)
     t1 = time.perf_counter()
-    rc1 = orc.zkp_oracle_prove_range_batch(u64(k), P(v1), P(mn1), P(mx1), 64, P(sd1), P(out1), u64(PROOF_BYTES), P(len1), P(st1), 1)
+    assert orc.zkp_oracle_prove_range_batch(u64(k), P(v1), P(mn1), P(mx1), 64, P(sd1), P(out1), u64(1478), P(len1), P(st1), 1) == 0
     dt1 = time.perf_counter() - t1
-    assert rc1 == 0
     return {"value": sample / dt, "unit": "proofs/s", "cores": threads, "kind": "port",
-            "c1_single_thread": {"workload": "100 x prove_range(50, 0, 100), 1 thread (BASELINE configs[0])", "ms_per_proof": dt1 / k * 1e3,
-                                 "proofs_per_second": k / dt1},
-            "sample": "first %d ops of the same 4096-op workload, oracle/c (scalar C restatement of upstream's Straus + "
-                      "generator-folding prover), OpenMP %d threads, %.1f s wall" % (sample, threads, dt)}
+            "c1_single_thread": {"workload": "100 x prove_range(50, 0, 100), 1 thread (BASELINE configs[0])", "ms_per_proof": dt1 / k * 1e3},
+            "sample": "first %d ops of the same 4096-op mixed batch (%d each of range / equality / membership(16) / improvement) through oracle/c's "
+                      "process_batch port, OpenMP %d threads, %.1f s wall = %.0f core-seconds" % (sample, sample // 4, threads, dt, dt * threads)}
 
 
 def main():
@@ -82,23 +95,23 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-overlap-leg", action="store_true", help="skip the extra leg that repeats the K steps with two batches in flight")
-    ap.add_argument("--pipeline", type=int, default=1,
-                    help="batches in flight: step k is issued on caller stream k %% P with its own output buffers (1 = strictly one after another; "
-                         "the library keeps at most 2 in flight)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs reported beside the contract's line (host buffers, C2/C3/C4 on their own)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the driver's runs) or gloo (rehearsing N > 1 on a box with fewer GPUs)")
     ap.add_argument("--cpu-sample", type=int, default=1024)
-    ap.add_argument("--window-budget", type=int, default=0)
-    ap.add_argument("--subbatches", type=int, default=0)
-    ap.add_argument("--msm-variant", type=int, default=0)
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _relaunch(args.gpus)
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import numpy as np
     import torch
     import torch.distributed as dist
+    from libzkp_amd import _native, workloads as wl
 
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -108,46 +121,42 @@ def main():
     if os.environ.get("ZKP_BENCH_DEVICE") is not None:          # rehearsal only: several ranks on one GPU
         local_rank = int(os.environ["ZKP_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
-    from libzkp_amd import _native
     L = _native.lib()
-    if args.window_budget:
-        L.zkp_hip_set_window_budget(args.window_budget)
-    if args.subbatches:
-        L.zkp_hip_set_subbatches(args.subbatches)
-    if args.msm_variant:
-        L.zkp_hip_set_msm_variant(args.msm_variant)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     _native.check(L.zkp_hip_init(local_rank), "zkp_hip_init")
+    for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")):      # ONE trusted setup for every rank: the committed test keys
+        blob = open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
+        _native.check(L.zkp_hip_groth16_load_key(kind, blob, len(blob)), "zkp_hip_groth16_load_key")
 
     n = args.batch
-    v, mn, mx, seeds = make_workload(n, 1 + rank)
-    dev = torch.device("cuda", local_rank)
-    d_v = torch.from_numpy(v.view(np.int64)).to(dev)
-    d_mn = torch.from_numpy(mn.view(np.int64)).to(dev)
-    d_mx = torch.from_numpy(mx.view(np.int64)).to(dev)
-    d_seeds = torch.from_numpy(seeds).to(dev)
-    P = max(1, min(args.pipeline, 2))
-    outs = [(torch.zeros((n, PROOF_BYTES), dtype=torch.uint8, device=dev), torch.zeros(n, dtype=torch.int32, device=dev),
-             torch.zeros(n, dtype=torch.int32, device=dev)) for _ in range(2)]
-    d_out, d_len, d_st = outs[0]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]   # non-default streams: their handles are non-NULL, so the library orders its work on them
-    stream = streams[0]
-    issued = [0]
+    ops, lists, seeds = wl.mixed_ops(n, 5 + rank)
+    counts = {k: int((ops["kind"] == c).sum()) for k, c in (("range", 1), ("equality", 2), ("membership", 4), ("improvement", 5))}
+    h = ctypes.c_void_p()
+    _native.check(L.zkp_hip_batch_stage(n, P(ops), P(lists), P(seeds), ctypes.byref(h)), "zkp_hip_batch_stage")      # inputs resident in HBM from here on
+    cap = int(L.zkp_hip_batch_max_bytes(h))
+    gathered = mine = None
+    if world > 1:
+        caps = [torch.zeros(1, dtype=torch.int64, device=dev if args.dist_backend == "nccl" else "cpu") for _ in range(world)]
+        dist.all_gather(caps, torch.tensor([cap], dtype=torch.int64, device=caps[0].device))
+        slot = max(int(c.item()) for c in caps)
+        gdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
+        mine = torch.zeros(slot, dtype=torch.uint8, device=dev)
+        gathered = torch.zeros(world * slot, dtype=torch.uint8, device=gdev)
 
-    def step(P=P):
-        k = issued[0] % P
-        issued[0] += 1
-        o, ln, stt = outs[k]
-        rc = L.zkp_hip_prove_range_batch_device(n, d_v.data_ptr(), d_mn.data_ptr(), d_mx.data_ptr(), 64, d_seeds.data_ptr(),
-                                                o.data_ptr(), PROOF_BYTES, ln.data_ptr(), stt.data_ptr(),
-                                                ctypes.c_void_p(streams[k].cuda_stream), None)
-        _native.check(rc, "zkp_hip_prove_range_batch_device")
-        return streams[k]
+    def step():
+        _native.check(L.zkp_hip_batch_prove(h), "zkp_hip_batch_prove")
+        if world > 1:                                                # the node-level process_batch hands every proof back: gather the packed proofs
+            s = torch.cuda.current_stream()
+            _native.check(L.zkp_hip_batch_device_results(h, 0, mine.data_ptr(), mine.numel(), None, None, ctypes.c_void_p(s.cuda_stream)), "device_results")
+            dist.all_gather_into_tensor(gathered, mine if gathered.is_cuda else mine.cpu())
+            s.synchronize()
 
     def barrier():
         torch.cuda.synchronize()
@@ -155,93 +164,106 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()
     L.zkp_hip_profile_enable(1)
-    L.zkp_hip_profile_read(None, None, None, 1)
-    issued[0] = 0
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    for k in range(3):
+        L.zkp_hip_profile_read_kernel(k, None, None, None, 1)
+    step_ms = []
     t0 = time.perf_counter()
-    evs[0].record(stream)
     for k in range(args.steps):
-        evs[k + 1].record(step())
+        ts = time.perf_counter()
+        step()
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     barrier()
     dt = time.perf_counter() - t0
-    msm_ms, msm_launches, msm_adds = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
-    L.zkp_hip_profile_read(ctypes.byref(msm_ms), ctypes.byref(msm_launches), ctypes.byref(msm_adds), 1)
+    prof = []
+    for k in range(3):
+        ms, launches, adds = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+        L.zkp_hip_profile_read_kernel(k, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(adds), 1)
+        prof.append((ms.value, launches.value, adds.value))
     L.zkp_hip_profile_enable(0)
-    if P == 1:
-        step_ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps)]
-    else:            # batches overlap: per-batch completion intervals alternate, so report the mean interval
-        step_ms = [dt / args.steps * 1e3]
 
-    # Beside the contract's line: the same K steps again with two batches in flight (the caller alternates two streams and
-    # two output buffers), which is how a server feeding batch after batch calls the library.  Reported separately
-    # because overlapped launches blur the per-launch durations the roofline is computed from.
-    dt2 = None
+    # correctness guard inside the bench: every op of the last step succeeded and the sizes are the expected ones
+    out = np.zeros(cap, dtype=np.uint8); off = np.zeros(n + 1, dtype=np.uint64); st = np.zeros(n, dtype=np.int32)
+    rc = _native.check(L.zkp_hip_batch_fetch(h, P(out), cap, P(off), P(st)), "zkp_hip_batch_fetch")
+    assert rc == 0 and not st.any()
+    lens = np.diff(off.astype(np.int64))
+    assert (lens[ops["kind"] == 1] == 1478).all() and (lens[ops["kind"] == 2] == 298).all() and (lens[ops["kind"] == 4] == 430).all() and (lens[ops["kind"] == 5] > 2000).all()
+    out_bytes = int(off[n])
+
+    extra = {}
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-    if P == 1 and not args.no_overlap_leg and not under_profiler:     # a profile of this command must hold the serial steps only
-        issued[0] = 0
-        step(2); step(2)
-        barrier()
-        issued[0] = 0
-        t1 = time.perf_counter()
-        for k in range(args.steps):
-            step(2)
-        barrier()
-        dt2 = time.perf_counter() - t1
-
-    # correctness guard inside the bench: every op succeeded
-    for o, ln, stt in outs[: 2 if dt2 is not None else P]:
-        assert int(stt.abs().sum().item()) == 0 and int((ln != PROOF_BYTES).sum().item()) == 0
+    if rank == 0 and not args.no_extra_legs and not under_profiler:     # a profile of this command holds the timed steps only
+        def timed(f, reps):
+            f()
+            ts = []
+            for _ in range(reps):
+                t = time.perf_counter(); f(); ts.append(time.perf_counter() - t)
+            return statistics.median(ts)
+        hb_off = np.zeros(n + 1, dtype=np.uint64); hb_st = np.zeros(n, dtype=np.int32)
+        t_hb = timed(lambda: _native.check(L.zkp_hip_process_batch(n, P(ops), P(lists), P(seeds), P(out), cap, P(hb_off), P(hb_st)), "process_batch"), 8)
+        extra["host_buffers"] = {"value": n / t_hb, "unit": "proofs/s", "ms_per_batch": t_hb * 1e3,
+                                 "note": "the same batch through zkp_hip_process_batch: bucketing + validation + pinned staging + H2D + proving + D2H of %d proof bytes; not `value`" % out_bytes}
+        legs = {}
+        for name, gen, cnt in (("C2_range_4096", wl.range_ops, 4096), ("C3_equality_4096", wl.equality_ops, 4096), ("C4_improvement_1024", wl.improvement_ops, 1024)):
+            o2, l2, s2 = gen(cnt)
+            h2 = ctypes.c_void_p()
+            _native.check(L.zkp_hip_batch_stage(cnt, P(o2), P(l2), P(s2), ctypes.byref(h2)), "stage")
+            t = timed(lambda: _native.check(L.zkp_hip_batch_prove(h2), "prove"), 5)
+            L.zkp_hip_batch_free(h2)
+            legs[name] = {"proofs_per_s": cnt / t, "ms_per_batch": t * 1e3}
+        extra["other_configs_staged"] = legs
+    L.zkp_hip_batch_free(h)
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        if dt2 is not None:
-            t = torch.tensor([dt2], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = float(t.item())
 
     if rank == 0:
         total = world * args.steps * n
-        avg_launch_ms = msm_ms.value / max(1, msm_launches.value)
-        # algorithmic bytes one MSM launch must move: SURVEY 8(d) per-proof bytes x proofs the launch processes
-        algo_bytes_launch = ALGO_BYTES_PER_PROOF * n
-        achieved_gbs = algo_bytes_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-        fe_mul_rate_g = msm_adds.value * FE_MUL_PER_POINT_ADD / (msm_ms.value * 1e-3) / 1e9 if msm_ms.value > 0 else 0.0
-        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (they cannot run inside this process);
-        # the committed summary of the latest pass is quoted here with its source
+        ed, g1, g2 = prof
+        g1_avg_ms = g1[0] / max(1, g1[1])
+        # algorithmic bytes one G1 MSM launch must move: an equality launch serves its 346 B/proof ops, a membership
+        # launch its 598 B/proof ops; the steps alternate one of each, so the per-launch average is the mean of the two
+        algo_launch = (ALGO_BYTES["equality"] * counts["equality"] + ALGO_BYTES["membership16"] * counts["membership"]) / 2.0
+        achieved = algo_launch / (g1_avg_ms * 1e-3) / 1e9 if g1_avg_ms > 0 else 0.0
+        fq_rate = g1[2] * FQ_MUL_PER_G1_MADD / (g1[0] * 1e-3) / 1e9 if g1[0] > 0 else 0.0
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
         res = {
-            "metric": "proofs/sec (whole node), 4096-op prove_range(v,0,2^32) batch per GPU",
+            "metric": "proofs/sec (whole node) + ms/proof p50, 4096-proof mixed batch (range / equality / membership / improvement) per MI355X",
             "value": total / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 limbs (25.5-bit radix GF(2^255-19), 8x32 Montgomery mod l)", "data": "synthetic",
-            "config": {"workload": "process_batch of %d prove_range(v, 0, 2^32), n_bits=64, seed 1 (BASELINE.md C2)" % n,
-                       "ops_per_gpu_per_step": n, "proof_bytes": PROOF_BYTES, "sharding": "independent ops per rank, no collective",
-                       "batches_in_flight": P},
+            "dtype": "u32/u64 integer limbs (10x25.5-bit GF(2^255-19), 10x26-bit BN254 Fq, 8x32-bit Fr and scalars mod l, 2x64-bit f128)", "data": "synthetic",
+            "config": {"workload": "process_batch of %d mixed ops, i mod 4 = prove_range(v,0,2^32) / prove_equality / prove_membership(16-element set) / "
+                                   "prove_improvement, seed 5 (BASELINE.md C5's mix at the metric's 4096-op size)" % n,
+                       "ops_per_gpu_per_step": n, "ops_by_variant": counts, "proof_bytes_per_step": out_bytes,
+                       "timed_region": "zkp_hip_batch_prove on a batch staged in HBM; packed proofs + offsets left in HBM"
+                                       + ("; RCCL all_gather of every rank's packed proofs" if world > 1 else ""),
+                       "sharding": "independent ops, one 4096-op batch per rank, no exchange inside the proving"},
             "ms_per_proof_p50": statistics.median(step_ms) / n,
             "ms_per_batch_p50": statistics.median(step_ms),
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_msm_dma<EdMsm>",
-                         "avg_launch_ms": avg_launch_ms, "launches": msm_launches.value,
-                         "algorithmic_bytes_per_launch": algo_bytes_launch,
-                         "note": "integer-ALU-bound kernel (SURVEY 8d): see roofline_valu"},
-            "roofline_valu": {"bound": "valu-int", "achieved": fe_mul_rate_g, "peak": FE_MUL_PEAK_G, "unit": "G field-mul/s",
-                              "frac": fe_mul_rate_g / FE_MUL_PEAK_G, "kernel": "k_msm_dma<EdMsm>",
-                              "msm_share_of_step": msm_ms.value / (dt * 1e3) if world == 1 else None},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_msm_dma<G1Msm>",
+                         "avg_launch_ms": g1_avg_ms, "launches": g1[1], "algorithmic_bytes_per_launch": algo_launch,
+                         "share_of_step": g1[0] / (dt * 1e3) if world == 1 else None,
+                         "note": "integer-ALU-bound kernel (SURVEY 8d): see roofline_valu; launch durations are taken on the kernel's own stream while the "
+                                 "other variants' kernels share the GPU"},
+            "roofline_valu": {"bound": "valu-int", "achieved": fq_rate, "peak": FQ_MUL_PEAK_G, "unit": "G BN254-Fq products/s", "frac": fq_rate / FQ_MUL_PEAK_G,
+                              "kernel": "k_msm_dma<G1Msm>", "point_additions_per_step": g1[2] / max(1, args.steps),
+                              "peak_source": "profiles/r02_fe_microbench.json (v_mad_u64_u32 issue rate; 200 per lazily reduced Fq product)"},
+            "other_msm_kernels": {
+                "k_msm_dma<G2Msm>": {"avg_launch_ms": g2[0] / max(1, g2[1]), "launches": g2[1], "ms_per_step": g2[0] / max(1, args.steps)},
+                "k_msm_dma<EdMsm>": {"avg_launch_ms": ed[0] / max(1, ed[1]), "launches": ed[1], "ms_per_step": ed[0] / max(1, args.steps),
+                                     "valu_frac": (ed[2] * 7 / (ed[0] * 1e-3) / 1e9 / FE_MUL_PEAK_G) if ed[0] > 0 else None}},
         }
-        if dt2 is not None:
-            res["two_batches_in_flight"] = {"value": total / dt2, "unit": "proofs/s", "ms_per_step": dt2 / args.steps * 1e3,
-                                            "note": "same K steps issued alternately on two streams; not the contract's value"}
+        res.update(extra)
         if not args.no_cpu_baseline:
             threads = min(len(os.sched_getaffinity(0)), 32)
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample, threads)
@@ -249,6 +271,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    L.zkp_hip_shutdown()
 
 
 if __name__ == "__main__":

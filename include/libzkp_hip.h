@@ -190,6 +190,11 @@ int zkp_hip_process_batch(uint64_t n, const zkp_hip_op* ops, const uint64_t* lis
  * zkp_hip_improvement_max_bytes()): callers size `out` with it instead of proving twice.  No device work. */
 int zkp_hip_process_batch_bytes(uint64_t n, const zkp_hip_op* ops, uint64_t* max_total);
 
+/* How the batch calls spread ops over GPUs: shard_of_op[i] = the shard that proves op i when `shards` shards are
+ * registered.  Every variant's ops, in the caller's order, are cut into `shards` contiguous slices of equal size (+-1), so all
+ * GPUs run the same kernel mix.  Pure host logic: needs no device. */
+int zkp_hip_plan_shards(uint64_t n, const zkp_hip_op* ops, uint32_t shards, uint32_t* shard_of_op);
+
 /* The three phases of zkp_hip_process_batch as separate calls.  A staged batch is the device-side counterpart of the
  * reference's ProofBatch (composition.rs:337-413, filled by batch_add_*, batch.rs:40-108): ops bucketed by variant, validated
  * (validation.rs), cut into per-shard slices and uploaded, i.e. resident in HBM.  zkp_hip_batch_prove runs the whole batch on
@@ -200,6 +205,11 @@ int zkp_hip_batch_stage(uint64_t n, const zkp_hip_op* ops, const uint64_t* lists
 int zkp_hip_batch_prove(zkp_hip_batch* batch);
 uint64_t zkp_hip_batch_max_bytes(const zkp_hip_batch* batch);
 int zkp_hip_batch_fetch(zkp_hip_batch* batch, uint8_t* out, uint64_t out_cap, uint64_t* out_off, int32_t* status);
+/* Device-resident results of a proved batch, shard by shard (a multi-process driver gathers them with RCCL instead of going
+ * through the host): copies shard `shard`'s packed proofs -- its ops in ascending op order -- into d_out (device memory, cap
+ * >= zkp_hip_batch_max_bytes) and its n_ops + 1 byte offsets into d_out_off (device, may be NULL), ordered on `stream` (a
+ * hipStream_t; NULL = the shard's own stream, synchronised before return). */
+int zkp_hip_batch_device_results(zkp_hip_batch* batch, uint32_t shard, uint8_t* d_out, uint64_t cap, uint64_t* d_out_off, uint64_t* n_ops, void* stream);
 void zkp_hip_batch_free(zkp_hip_batch* batch);
 
 /* Kernel timing for the roofline line of bench.py: when enabled, every launch of the dominant kernel

@@ -14,7 +14,7 @@ from .api import (  # noqa: F401
     batch_add_threshold_proof, batch_add_membership_proof, batch_add_improvement_proof, batch_add_consistency_proof,
     process_batch, get_batch_status, clear_batch, benchmark_proof_generation, benchmark_proof_generation_numeric,
     open_batch_from_store, refresh_batch_from_store, export_batch_to_file, import_batch_from_file,
-    ZkpBackendError, shutdown,
+    ZkpBackendError, shutdown, clear_cache, get_cache_stats, get_performance_metrics, prove_range_cached, prove_threshold_optimized,
 )
 from .batch_store import set_batch_store_dir, get_batch_store_dir, list_batch_ids_in_store  # noqa: F401
 from .composite import (  # noqa: F401
@@ -37,4 +37,5 @@ __all__ = [
     "open_batch_from_store", "refresh_batch_from_store", "export_batch_to_file", "import_batch_from_file",
     "set_batch_store_dir", "get_batch_store_dir", "list_batch_ids_in_store",
     "NativeError", "ZkpBackendError", "shutdown",
+    "clear_cache", "get_cache_stats", "get_performance_metrics", "prove_range_cached", "prove_threshold_optimized",
 ]

@@ -19,7 +19,7 @@ EXPORTS = (
     "zkp_hip_prove_improvement_batch_device", "zkp_hip_verify_range_batch", "zkp_hip_verify_threshold_batch", "zkp_hip_verify_consistency_batch", "zkp_hip_verify_equality_batch", "zkp_hip_verify_membership_batch",
     "zkp_hip_verify_improvement_batch", "zkp_hip_process_batch", "zkp_hip_profile_enable", "zkp_hip_profile_read", "zkp_hip_set_window_budget", "zkp_hip_set_subbatches", "zkp_hip_set_msm_variant",
     "zkp_hip_init_devices", "zkp_hip_device_count", "zkp_hip_use_device", "zkp_hip_process_batch_bytes", "zkp_hip_batch_stage", "zkp_hip_batch_prove", "zkp_hip_batch_max_bytes",
-    "zkp_hip_batch_fetch", "zkp_hip_batch_free", "zkp_hip_profile_read_kernel",
+    "zkp_hip_batch_fetch", "zkp_hip_batch_free", "zkp_hip_profile_read_kernel", "zkp_hip_batch_device_results", "zkp_hip_plan_shards",
 )
 
 _lib = None
@@ -134,6 +134,10 @@ def lib():
         L.zkp_hip_batch_max_bytes.restype = u64
         L.zkp_hip_batch_fetch.argtypes = [vp, vp, u64, vp, vp]
         L.zkp_hip_batch_fetch.restype = ctypes.c_int
+        L.zkp_hip_batch_device_results.argtypes = [vp, u32, vp, u64, vp, ctypes.POINTER(u64), vp]
+        L.zkp_hip_batch_device_results.restype = ctypes.c_int
+        L.zkp_hip_plan_shards.argtypes = [u64, vp, u32, vp]
+        L.zkp_hip_plan_shards.restype = ctypes.c_int
         L.zkp_hip_batch_free.argtypes = [vp]
         L.zkp_hip_batch_free.restype = None
         L.zkp_hip_profile_read_kernel.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.c_int]

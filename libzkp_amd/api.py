@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-from . import _native, batch_store
+from . import _native, perf, batch_store
 
 U64_MAX = 2**64 - 1
 
@@ -819,7 +819,9 @@ def benchmark_proof_generation_numeric(proof_type, iterations):
     for _ in range(iterations):
         t0 = time.perf_counter()
         runners[proof_type]()
-        times.append((time.perf_counter() - t0) * 1e3)
+        dt = time.perf_counter() - t0
+        perf.METRICS.record_operation(proof_type + "_proof", dt)                  # mod.rs:113-123
+        times.append(dt * 1e3)
     if not times:
         raise ValueError("no successful proof generations")
     total = sum(times)
@@ -830,6 +832,38 @@ def benchmark_proof_generation_numeric(proof_type, iterations):
         "total_time_ms": total, "avg_time_ms": avg, "min_time_ms": min(times), "max_time_ms": max(times),
         "std_dev_ms": var ** 0.5, "proofs_per_second": len(times) / (total / 1e3), "throughput_ms_per_proof": total / len(times),
     }
+
+
+# ---------------------------------------------------------------- cache / metrics entry points (advanced/mod.rs:25-80,175-191,218-221)
+def clear_cache():
+    perf.CACHE.clear()
+
+
+def get_cache_stats():
+    return {"size": perf.CACHE.size()}
+
+
+def get_performance_metrics():
+    return perf.performance_metrics()
+
+
+def prove_range_cached(value, min, max):  # noqa: A002
+    """advanced/mod.rs:175-191: a hit returns the cached proof bytes; a miss proves, records the timing and stores."""
+    value, mn, mx = _check_u64("value", value), _check_u64("min", min), _check_u64("max", max)
+    key = perf.generate_cache_key("range_proof", ("%d:%d:%d" % (value, mn, mx)).encode())
+    hit = perf.CACHE.get(key)
+    if hit is not None:
+        return hit
+    t0 = time.perf_counter()
+    proof = prove_range(value, mn, mx)
+    perf.METRICS.record_operation("range_proof", time.perf_counter() - t0)
+    perf.CACHE.put(key, proof)
+    return proof
+
+
+def prove_threshold_optimized(values, threshold):
+    """advanced/mod.rs:218-221: delegates to prove_threshold."""
+    return prove_threshold(values, threshold)
 
 
 def benchmark_proof_generation(proof_type, iterations):
