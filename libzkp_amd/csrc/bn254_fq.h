@@ -48,7 +48,30 @@ ZKP_HD inline fq fq_mul(const fq& a, const fq& b) {
     r.v[9] = (uint32_t)acc;
     return r;
 }
-ZKP_HD inline fq fq_sq(const fq& a) { return fq_mul(a, a); }
+// Squaring: the product columns are symmetric, so each pair a_j a_(i-j) is formed once with a doubled limb (55 products
+// instead of 100; the 100 reduction products stay).  Same input / output contract as fq_mul (limbs < 2^29 doubled still
+// fit 32 bits, column sums are term for term those of fq_mul(a, a)).
+ZKP_HD inline fq fq_sq(const fq& a) {
+    uint32_t m[10], d[10]; fq r; uint64_t acc = 0;
+    ZKP_UNROLL for (int i = 0; i < 10; i++) d[i] = a.v[i] << 1;
+    ZKP_UNROLL for (int i = 0; i < 10; i++) {
+        ZKP_UNROLL for (int j = 0; 2 * j < i; j++) acc += (uint64_t)d[j] * a.v[i - j];
+        if ((i & 1) == 0) acc += (uint64_t)a.v[i / 2] * a.v[i / 2];
+        ZKP_UNROLL for (int j = 0; j < i; j++) acc += (uint64_t)m[j] * fq_pl(i - j);
+        m[i] = ((uint32_t)acc * ZKP_FQ_N0) & ZKP_FQ_MASK;
+        acc += (uint64_t)m[i] * fq_pl(0);
+        acc >>= 26;
+    }
+    ZKP_UNROLL for (int i = 10; i < 19; i++) {
+        ZKP_UNROLL for (int j = i - 9; 2 * j < i; j++) acc += (uint64_t)d[j] * a.v[i - j];
+        if ((i & 1) == 0) acc += (uint64_t)a.v[i / 2] * a.v[i / 2];
+        ZKP_UNROLL for (int j = i - 9; j < 10; j++) acc += (uint64_t)m[j] * fq_pl(i - j);
+        r.v[i - 10] = (uint32_t)acc & ZKP_FQ_MASK;
+        acc >>= 26;
+    }
+    r.v[9] = (uint32_t)acc;
+    return r;
+}
 
 // limb-wise (lazy) operations
 ZKP_HD inline fq fq_add_l(const fq& a, const fq& b) { fq r; ZKP_UNROLL for (int i = 0; i < 10; i++) r.v[i] = a.v[i] + b.v[i]; return r; }

@@ -39,6 +39,27 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) <= exported
 
 
+def test_rust_bindings_declare_every_symbol():
+    """rust/hip_ffi.rs (unbuilt source: no cargo in the image) must declare exactly the header's symbols."""
+    rs = open(os.path.join(ROOT, "rust", "hip_ffi.rs")).read()
+    assert sorted(set(re.findall(r"pub fn (zkp_hip_[a-z_0-9]+)\s*\(", rs))) == declared_symbols()
+
+
+def test_cpp_caller_of_every_entry_point_builds_and_fails_loudly_without_gpu():
+    """tests/abi/abi_call_all.cpp calls all entry points through the header alone.  Here: it compiles and links against the
+    built library, names every declared symbol, and -- on a box without a GPU -- reports the missing device instead of
+    computing anything on the CPU.  The GPU tier runs it for real (tests/test_gpu_abi_cpp.py)."""
+    import __graft_entry__ as ge
+    exe = ge.build_abi_caller()
+    src = open(os.path.join(ROOT, "tests", "abi", "abi_call_all.cpp")).read()
+    assert sorted(set(re.findall(r"CALLED\((zkp_hip_[a-z_0-9]+)\)", src))) == declared_symbols()
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the real run is in the gpu tier")
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True)
+    assert r.returncode != 0 and "no HIP device available" in r.stderr
+
+
 def test_product_path_fails_loudly_without_gpu():
     """No silent CPU fallback: without a device the call errors out (skipped when a GPU is present)."""
     import torch

@@ -78,6 +78,13 @@ def mul(a, b):
 
 
 def sq(a):
+    """fq_sq: pairs are formed once with a doubled limb; the column sums are term for term those of mul(a, a)"""
+    assert all(2 * x < 1 << 32 for x in a.l), "doubled limb overflows 32 bits"
+    for col in range(19):
+        acc = sum(2 * a.l[j] * a.l[col - j] for j in range(10) if 0 <= col - j < 10 and 2 * j < col)
+        acc += a.l[col // 2] ** 2 if col % 2 == 0 else 0
+        full = sum(a.l[j] * a.l[col - j] for j in range(10) if 0 <= col - j < 10)
+        assert acc == full
     return mul(a, a)
 
 

@@ -246,6 +246,61 @@ static void printA(const FeA& x) { printf("A:"); for (int i = 0; i < 8; i++) pri
 static void printB(const FeB& x) { printf("B:"); for (int i = 0; i < 10; i++) printf("%u%s", x.v[i], i < 9 ? "," : ""); }
 static void printC(const FeC& x) { printf("C:"); for (int i = 0; i < 12; i++) printf("%.0f%s", ldexp(x.v[i], -P12[i]), i < 11 ? "," : ""); }
 
+// ---------------------------------------------------------------- raw issue rate of v_mad_u64_u32
+// 8 independent 64-bit accumulators per lane, 16 x 8 mads per loop trip, inline asm so nothing is folded away: anchors the
+// field-multiplication ceilings (100 mads per GF(2^255-19) product, 200 per lazily reduced BN254 Fq product) to an
+// instruction rate.  Also the same loop with full-rate v_add_u32 for the clock the chip holds on this kind of code.
+__global__ void __launch_bounds__(256) k_mad_rate(uint64_t* out, uint32_t a, uint32_t b, int iters) {
+    uint64_t acc[8];
+    for (int k = 0; k < 8; k++) acc[k] = threadIdx.x * 8 + k;
+    uint32_t x = a + threadIdx.x, y = b;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[k]) : "v"(x), "v"(y) : "vcc");
+        }
+    }
+    uint64_t s = 0; for (int k = 0; k < 8; k++) s ^= acc[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) k_add_rate(uint32_t* out, uint32_t a, int iters) {
+    uint32_t acc[8];
+    for (int k = 0; k < 8; k++) acc[k] = threadIdx.x * 8 + k;
+    uint32_t x = a + threadIdx.x;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) asm volatile("v_add_u32 %0, %1, %0" : "+v"(acc[k]) : "v"(x));
+        }
+    }
+    uint32_t s = 0; for (int k = 0; k < 8; k++) s ^= acc[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+static void run_rates(int blocks, int iters) {
+    uint64_t* d; CK(hipMalloc(&d, (size_t)blocks * 256 * 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const double simds = prop.multiProcessorCount * 4.0;
+    for (int which = 0; which < 2; which++) {
+        float best = 1e30f;
+        for (int rep = 0; rep < 5; rep++) {
+            CK(hipEventRecord(e0));
+            if (which == 0) k_mad_rate<<<blocks, 256>>>(d, 12345u, 678901u, iters); else k_add_rate<<<blocks, 256>>>((uint32_t*)d, 12345u, iters);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+        }
+        const double ops = (double)blocks * 256 * iters * 128.0;
+        const double rate = ops / (best * 1e-3);
+        // wave-instructions per second per SIMD; at clock f a full-rate op issues one wave-instruction per 4 cycles
+        const double per_simd = rate / 64.0 / simds;
+        printf("{\"variant\": \"%s\", \"blocks\": %d, \"iters\": %d, \"ms\": %.3f, \"t_lane_ops_per_s\": %.3f, \"wave_instr_per_s_per_simd\": %.4g, \"cus\": %d, \"clock_mhz_reported\": %d}\n",
+               which == 0 ? "v_mad_u64_u32_issue_rate" : "v_add_u32_issue_rate", blocks, iters, best, rate / 1e12, per_simd, prop.multiProcessorCount, prop.clockRate / 1000);
+    }
+    CK(hipFree(d));
+}
+
 int main(int argc, char** argv) {
     int blocks = argc > 1 ? atoi(argv[1]) : 256 * 8;
     int iters = argc > 2 ? atoi(argv[2]) : 2000;
@@ -263,6 +318,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 10; i++) ib[n].v[i] = (uint32_t)(rnd() & ((i & 1) ? 0x1ffffffu : 0x3ffffffu));
         for (int i = 0; i < 12; i++) { int w = P12[i + 1] - P12[i]; ic[n].v[i] = ldexp((double)(rnd() & ((1ull << w) - 1)), P12[i]); }
     }
+    run_rates(blocks, iters);
     run<FeA, mulA>("A_8x32", ia, blocks, iters, printA);
     run<FeB, mulB>("B_10x25.5", ib, blocks, iters, printB);
     run<FeB, mulB1>("B1_10x25.5_seeded_carry", ib, blocks, iters, printB);
