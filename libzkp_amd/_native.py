@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libzkp_hip.so")
+LIB_PATH = os.environ.get("ZKP_HIP_LIB") or os.path.join(_HERE, "lib", "libzkp_hip.so")      # ZKP_HIP_LIB: A/B builds (tools only)
 
 RANGE_PROOF_BYTES = 1478
 # symbols declared in include/libzkp_hip.h (checked by tests/test_abi.py)

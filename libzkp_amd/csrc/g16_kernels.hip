@@ -8,11 +8,14 @@ struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b
     static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int16_t)(word >> (16 * (w & 1u))); }
     using Acc = g1_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq>(); }
-    static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
-        const uint32_t* e = subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W;
+    static constexpr uint32_t GATHER_WAVES = 3; static constexpr bool GATHER_PREFETCH = true;      // k_msm_gather: 3 waves/SIMD, entries one step ahead
+    static __device__ __forceinline__ Acc accumulate_entry(const Acc& acc, int32_t d, const uint32_t* e) {
         g1_aff q; ZKP_UNROLL for (int k = 0; k < 10; k++) { q.x.v[k] = e[k]; q.y.v[k] = e[10 + k]; }
         q.y = fq_select(d < 0, fq_sub_k4(fq_zero(), q.y), q.y);          // 4p - y: limbs < 2^27, fine as a product operand
         return g1_madd_lazy(acc, q);
+    }
+    static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
+        return accumulate_entry(acc, d, subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W);
     }
     static __device__ __forceinline__ void store(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const Acc& a) { st_g1_jac(p, idx, row, rows, a); }
     static __device__ __forceinline__ Acc load(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) { return ld_g1_jac(p, idx, row, rows); }
@@ -24,10 +27,13 @@ struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
     static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int16_t)(word >> (16 * (w & 1u))); }
     using Acc = g2_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq2>(); }
-    static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
-        const uint32_t* e = subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W;
+    static constexpr uint32_t GATHER_WAVES = 2; static constexpr bool GATHER_PREFETCH = false;     // k_msm_gather: 256 VGPRs are taken by the addition itself
+    static __device__ __forceinline__ Acc accumulate_entry(const Acc& acc, int32_t d, const uint32_t* e) {
         g2_aff q; ZKP_UNROLL for (int k = 0; k < 10; k++) { q.x.c0.v[k] = e[k]; q.x.c1.v[k] = e[10 + k]; q.y.c0.v[k] = e[20 + k]; q.y.c1.v[k] = e[30 + k]; }
         return g2_madd_lazy(acc, q, d < 0);
+    }
+    static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
+        return accumulate_entry(acc, d, subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W);
     }
     static __device__ __forceinline__ void store(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const Acc& a) { st_g2_jac(p, idx, row, rows, a); }
     static __device__ __forceinline__ Acc load(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) { return ld_g2_jac(p, idx, row, rows); }
@@ -67,13 +73,16 @@ __global__ void __launch_bounds__(TW) k_mimc_commit(const uint64_t* values, uint
     uint32_t w[8]; fp_to_raw(w, h);
     g16_put_bytes(out + 32ull * i, w, 8);
 }
-// thread = (slot, window): entries e = 1..512 of 1024^window * Base as affine points (Montgomery coordinates)
+// thread = (slot, window): entries e = 1..NENT of 2^(WBITS window) * Base as affine points (Montgomery coordinates).  The
+// multiples are produced in Jacobian form eight at a time and converted with ONE field inversion per eight (Montgomery's
+// trick), which is what keeps a 4096-entry sub-table affordable at key load.
 template <class F, uint32_t AFF_W>
 __global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, uint32_t nslots, uint32_t* table) {
     const uint32_t t = blockIdx.x * TW + threadIdx.x;
     if (t >= nslots * G16_NWIN) return;
     const uint32_t slot = t / G16_NWIN, win = t % G16_NWIN;
-    constexpr uint32_t FW = AFF_W / 2;
+    constexpr uint32_t FW = AFF_W / 2, BATCH = 8;
+    static_assert(G16_NENT % BATCH == 0, "entries per sub-table must be a multiple of the inversion batch");
     Aff<F> base;
     {
         const uint32_t* b = bases + (size_t)slot * AFF_W;
@@ -84,11 +93,22 @@ __global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, u
     for (uint32_t i = 0; i < G16_WBITS * win; i++) q = jac_dbl(q);
     Jac<F> acc = q;
     uint32_t* dst = table + ((size_t)slot * G16_NWIN + win) * G16_NENT * AFF_W;
-    for (uint32_t e = 0; e < G16_NENT; e++) {
-        Aff<F> a; jac_to_aff(a, acc);
-        const uint32_t* ax = reinterpret_cast<const uint32_t*>(&a.x); const uint32_t* ay = reinterpret_cast<const uint32_t*>(&a.y);
-        for (uint32_t k = 0; k < FW; k++) { dst[(size_t)e * AFF_W + k] = ax[k]; dst[(size_t)e * AFF_W + FW + k] = ay[k]; }
-        acc = jac_add(acc, q);
+    for (uint32_t e0 = 0; e0 < G16_NENT; e0 += BATCH) {
+        Jac<F> pts[BATCH]; F zp[BATCH];
+        for (uint32_t k = 0; k < BATCH; k++) {
+            pts[k] = acc; acc = jac_add(acc, q);
+            zp[k] = k ? f_mul(zp[k - 1], pts[k].Z) : pts[k].Z;
+        }
+        F inv = f_inv(zp[BATCH - 1]);
+        for (int k = BATCH - 1; k >= 0; k--) {
+            const F zi = k ? f_mul(inv, zp[k - 1]) : inv;
+            if (k) inv = f_mul(inv, pts[k].Z);
+            const F zi2 = f_sq(zi);
+            Aff<F> a; a.x = f_mul(pts[k].X, zi2); a.y = f_mul(pts[k].Y, f_mul(zi2, zi));
+            const uint32_t* ax = reinterpret_cast<const uint32_t*>(&a.x); const uint32_t* ay = reinterpret_cast<const uint32_t*>(&a.y);
+            uint32_t* o = dst + (size_t)(e0 + k) * AFF_W;
+            for (uint32_t j = 0; j < FW; j++) { o[j] = ax[j]; o[FW + j] = ay[j]; }
+        }
     }
 }
 
@@ -104,6 +124,8 @@ __global__ void __launch_bounds__(TW) k_g16_serialize(bool g2, const uint32_t* j
 
 template __global__ void k_msm_dma<G1Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_msm_dma<G2Msm>(MsmView, uint32_t, uint32_t);
+template __global__ void k_msm_gather<G1Msm>(MsmView, uint32_t, uint32_t);
+template __global__ void k_msm_gather<G2Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_sum_t<G1Msm>(ReduceView, uint32_t*);
 template __global__ void k_sum_t<G2Msm>(ReduceView, uint32_t*);
 template __global__ void k_g16_build_table<fq, 20>(const uint32_t*, uint32_t, uint32_t*);
@@ -133,15 +155,23 @@ void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uin
 }
 // > 64 KB of dynamic LDS needs the opt-in attribute; once per HIP device (called when a shard creates its Groth16 state)
 hipError_t g16_prepare_device() {
+    if constexpr (G16_WBITS > 10) return hipSuccess;           // the gather kernel uses no LDS
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<G1Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<G1Msm>());
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<G2Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<G2Msm>());
 }
+uint32_t g16_msm_rows_per_block(bool g2) { return G16_WBITS > 10 ? 256u : (g2 ? G2Msm::TB : G1Msm::TB); }
+uint32_t g16_msm_blocks_per_cu(bool g2) { return G16_WBITS > 10 ? (g2 ? G2Msm::GATHER_WAVES : G1Msm::GATHER_WAVES) : 1u; }
 void g16_launch_msm(bool g2, const MsmView& m, hipStream_t st) {
-    const uint32_t tb = g2 ? G2Msm::TB : G1Msm::TB;
+    const uint32_t tb = g16_msm_rows_per_block(g2);
     const uint32_t ngroups = (m.rows + tb - 1) / tb, nblocks = m.nchunks * ngroups, grid = ((nblocks + 7) / 8) * 8;
-    if (!g2) k_msm_dma<G1Msm><<<grid, G1Msm::TB, msm_lds_bytes<G1Msm>(), st>>>(m, ngroups, nblocks);
-    else k_msm_dma<G2Msm><<<grid, G2Msm::TB, msm_lds_bytes<G2Msm>(), st>>>(m, ngroups, nblocks);
+    if constexpr (G16_WBITS > 10) {          // HBM-resident radix-2^13 tables, per-lane gathers
+        if (!g2) k_msm_gather<G1Msm><<<grid, 256, 0, st>>>(m, ngroups, nblocks);
+        else k_msm_gather<G2Msm><<<grid, 256, 0, st>>>(m, ngroups, nblocks);
+    } else {                                 // radix-1024 sub-tables streamed through LDS (A/B build)
+        if (!g2) k_msm_dma<G1Msm><<<grid, G1Msm::TB, msm_lds_bytes<G1Msm>(), st>>>(m, ngroups, nblocks);
+        else k_msm_dma<G2Msm><<<grid, G2Msm::TB, msm_lds_bytes<G2Msm>(), st>>>(m, ngroups, nblocks);
+    }
 }
 void g16_launch_sum(bool g2, const ReduceView& R, uint32_t* sums, hipStream_t st) {
     if (!g2) k_sum_t<G1Msm><<<dim3((R.rows + 63) / 64, R.ntargets), SUM_TB, 0, st>>>(R, sums);

@@ -13,9 +13,17 @@
 
 namespace zkp {
 
-// key-point tables: signed radix-1024 digits (13 words per scalar, two 16-bit digits per word), 26 windows of 512 affine
-// entries; a 64-bit value needs 7 windows
-constexpr uint32_t G16_WBITS = 10, G16_NWIN = 26, G16_NENT = 512, G16_DIGW = 13, G16_NWIN_U64 = 7;
+// Key-point tables: signed radix-2^13 digits (two 16-bit digits per word), 20 windows of 4096 affine entries per key point,
+// resident in HBM and gathered per lane (k_msm_gather): 20 mixed additions per 254-bit scalar where the LDS-streamed
+// radix-1024 tables of round 1 needed 26.  A 64-bit value needs 5 windows, a bit 1.  (ZKP_G16_WBITS=10 rebuilds the
+// radix-1024 layout: 26 windows of 512 entries, streamed through LDS by k_msm_dma -- kept for A/B measurements.)
+#ifndef ZKP_G16_WBITS
+#define ZKP_G16_WBITS 13
+#endif
+constexpr uint32_t G16_WBITS = ZKP_G16_WBITS, G16_NWIN = (254 + G16_WBITS) / G16_WBITS, G16_NENT = 1u << (G16_WBITS - 1),
+                   G16_DIGW = (G16_NWIN + 1) / 2, G16_NWIN_U64 = (64 + G16_WBITS) / G16_WBITS;
+static_assert(G16_NWIN * G16_WBITS >= 255 && G16_NWIN_U64 * G16_WBITS >= 65, "windows must cover the scalar and the recoding carry");
+ZKP_HD inline void g16_recode(uint32_t* packed, const sc& raw) { sc_recode_signed<(int)G16_WBITS, (int)G16_NWIN>(packed, raw); }
 
 
 constexpr uint32_t MIMC_ROUNDS = 110, G16_MAX_SET = 64;
@@ -35,10 +43,10 @@ ZKP_HD inline fr ld_fr_c(const uint32_t* p, uint32_t idx) { fr r; ZKP_UNROLL for
 ZKP_HD inline void g16_put_bytes(uint8_t* dst, const uint32_t* w, int nwords) {
     for (int i = 0; i < nwords; i++) { dst[4 * i] = (uint8_t)w[i]; dst[4 * i + 1] = (uint8_t)(w[i] >> 8); dst[4 * i + 2] = (uint8_t)(w[i] >> 16); dst[4 * i + 3] = (uint8_t)(w[i] >> 24); }
 }
-// packed signed radix-1024 digits of a Montgomery-form Fr element (canonical value < r < 2^254: 26 windows)
+// packed signed digits of a Montgomery-form Fr element (canonical value < r < 2^254)
 ZKP_HD inline void st_fr_digits(uint32_t* d, uint32_t idx, uint32_t row, uint32_t rows, const fr& x) {
     sc raw; fp_to_raw(raw.v, x);
-    uint32_t pk[G16_DIGW]; sc_recode_signed1024(pk, raw);
+    uint32_t pk[G16_DIGW]; g16_recode(pk, raw);
     uint32_t* q = d + (size_t)idx * G16_DIGW * rows + row;
     ZKP_UNROLL for (uint32_t k = 0; k < G16_DIGW; k++) q[(size_t)k * rows] = pk[k];
 }

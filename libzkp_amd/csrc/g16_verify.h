@@ -16,7 +16,7 @@ struct G16Vk {
     fq12 ml_alpha_beta;            // Miller loop value of (beta, -alpha): the constant factor of the check
     uint32_t n_ic;                 // gamma_abc_g1 length (1 + public inputs)
     const uint32_t* ic;            // [n_ic][20] affine points, Montgomery limbs
-    const uint32_t* ic_table;      // optional [n_ic][26 windows][512 entries][20]: entry e of window w = (e + 1) * 1024^w * IC_i (affine)
+    const uint32_t* ic_table;      // optional [n_ic][G16_NWIN windows][G16_NENT entries][20]: entry e of window w = (e + 1) * 2^(WBITS w) * IC_i (affine)
 };
 
 ZKP_HD inline uint32_t ld_u32_le(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -80,15 +80,20 @@ ZKP_HD inline g1_aff ld_ic(const G16Vk& vk, uint32_t i) {
     for (int k = 0; k < 10; k++) { p.x.v[k] = q[k]; p.y.v[k] = q[10 + k]; }
     return p;
 }
-// k * IC_i for a raw scalar of at most 10 * nwin - 1 bits: one mixed addition per non-zero signed radix-1024 digit when the
-// key carries window tables, the generic ladder otherwise (host emulation of large keys)
+// k * IC_i for a raw scalar that fits nwin windows: one mixed addition per non-zero signed radix-2^WBITS digit when the key
+// carries window tables (digits are recoded on the fly, low window first), the generic ladder otherwise (host emulation of
+// large keys)
 ZKP_HD_NOINLINE inline g1_jac g16_ic_mul(const G16Vk& vk, uint32_t i, const uint32_t k[8], uint32_t nwin) {
     if (vk.ic_table == nullptr) return jac_mul_raw(jac_from_aff(ld_ic(vk, i)), k);
-    sc raw; for (int j = 0; j < 8; j++) raw.v[j] = k[j];
-    uint32_t dig[G16_DIGW]; sc_recode_signed1024(dig, raw);
     g1_jac acc = jac_infinity<fq>();
+    uint32_t carry = 0;
     for (uint32_t w = 0; w < nwin; w++) {
-        const int32_t d = (int32_t)(int16_t)(dig[w >> 1] >> (16 * (w & 1u)));
+        const uint32_t bit = G16_WBITS * w, wd = bit >> 5, sh = bit & 31u;
+        uint32_t x = wd < 8 ? k[wd] >> sh : 0u;
+        if (sh + G16_WBITS > 32 && wd + 1 < 8) x |= k[wd + 1] << (32 - sh);
+        const uint32_t dd = (x & ((1u << G16_WBITS) - 1u)) + carry;            // 0 .. 2^WBITS
+        carry = dd > G16_NENT ? 1u : 0u;
+        const int32_t d = (int32_t)dd - (int32_t)(carry << G16_WBITS);         // [-(NENT - 1), NENT]
         if (d == 0) continue;
         const uint32_t* e = vk.ic_table + (((size_t)i * G16_NWIN + w) * G16_NENT + (uint32_t)((d < 0 ? -d : d) - 1)) * 20;
         g1_aff q; for (int j = 0; j < 10; j++) { q.x.v[j] = e[j]; q.y.v[j] = e[10 + j]; }

@@ -78,6 +78,60 @@ __global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint
 #endif
 }
 
+// ---- HBM-resident tables, per-lane gathers (Groth16 key points).  The tables are sized for HBM, not for LDS: radix 2^13
+// needs 4096 entries per (key point, window) -- 320 KB for G1, 640 KB for G2, tens of GB per key in total -- so each lane
+// fetches the one entry its digit selects straight from global memory (the workgroups that share a chunk sit on one XCD and
+// walk the same sub-tables at the same time, so a good part of the entries is served from that XCD's L2).  No LDS, no
+// barrier: a workgroup is four independent waves.  Loads are software-pipelined one step ahead when the point type has the
+// registers for it (T::GATHER_PREFETCH): the next entry's 16-byte pieces are issued before the current addition starts and
+// consumed ~10 us later; the digit word that selects them was fetched one step earlier still.
+template <class T>
+__global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, uint32_t ngroups, uint32_t nblocks) {
+    constexpr uint32_t V4 = T::AFF_W / 4;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per_xcd = (nblocks + 7) / 8;
+    const uint32_t linear = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (linear >= nblocks) return;
+    const uint32_t chunk = linear / ngroups, group = linear % ngroups;
+    const uint32_t row = group * 256u + tid;
+    const bool active = row < m.rows;
+    uint32_t s = m.chunk_begin[chunk], w = m.chunk_win0[chunk], left = m.chunk_nwin[chunk];
+    typename T::Acc acc = m.acc_init ? T::load(m.acc_init, 0, 0, 1) : T::identity();
+    const uint4* const table4 = reinterpret_cast<const uint4*>(m.table);
+    auto digit_word = [&](uint32_t slot, uint32_t win) -> uint32_t {
+        const uint32_t srow = m.slot_scalar ? m.slot_scalar[slot] : slot;
+        return active ? m.digits[((size_t)srow * T::DIGW + win / T::DIG_PER_WORD) * m.rows + row] : 0u;
+    };
+    auto fetch = [&](uint4* e, uint32_t slot, uint32_t win, int32_t d) {
+        if (d == 0) return;
+        const uint4* src = table4 + (((size_t)m.slot_base[slot] * T::NWIN + win) * T::NENT + (uint32_t)((d < 0 ? -d : d) - 1)) * V4;
+        ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) e[k] = src[k];
+    };
+    if (left == 0) { if (active) T::store(m.partial, chunk, row, m.rows, acc); return; }
+    uint32_t dw = digit_word(s, w);                               // the chunk may start in the middle of a word
+    int32_t d = T::digit(dw, w);
+    uint4 cur[V4], nxt[V4];
+    fetch(cur, s, w, d);
+    while (left) {
+        const uint32_t nwin = m.slot_nwin[s];
+        uint32_t ns = s, nw = w + 1;
+        if (nw == nwin) { ns = s + 1; nw = 0; }
+        int32_t dn = 0;
+        if (left > 1) {
+            if ((nw % T::DIG_PER_WORD) == 0) dw = digit_word(ns, nw);
+            dn = T::digit(dw, nw);
+            if constexpr (T::GATHER_PREFETCH) fetch(nxt, ns, nw, dn);
+        }
+        if (d != 0) acc = T::accumulate_entry(acc, d, reinterpret_cast<const uint32_t*>(cur));
+        if (left > 1) {
+            if constexpr (T::GATHER_PREFETCH) { ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) cur[k] = nxt[k]; }
+            else fetch(cur, ns, nw, dn);
+        }
+        s = ns; w = nw; d = dn; left--;
+    }
+    if (active) T::store(m.partial, chunk, row, m.rows, acc);
+}
+
 // Partial sums of one target: a block owns 64 consecutive rows, its 8 waves each add every 8th chunk partial for those
 // rows (lane = row: every load is a full 256-byte coalesced segment), then a 3-level tree through LDS joins the waves.
 static constexpr int SUM_TB = 512;

@@ -223,4 +223,19 @@ ZKP_HD inline void sc_recode_signed1024(uint32_t packed[13], const sc& raw) {
     }
 }
 
+// signed radix-2^WB recoding of a canonical raw scalar: ND digits in [-(2^(WB-1) - 1), 2^(WB-1)], two 16-bit digits per word
+// (WB <= 15; WB * ND must cover the scalar's bit length plus the carry).  WB = 10, ND = 26 is sc_recode_signed1024.
+template <int WB, int ND> ZKP_HD inline void sc_recode_signed(uint32_t* packed, const sc& raw) {
+    uint32_t carry = 0;
+    ZKP_UNROLL for (int j = 0; j < ND; j++) {
+        const int bit = WB * j, wd = bit >> 5, sh = bit & 31;
+        uint32_t x = wd < 8 ? raw.v[wd] >> sh : 0u;
+        if (sh + WB > 32 && wd + 1 < 8) x |= raw.v[wd + 1] << (32 - sh);
+        uint32_t d = (x & ((1u << WB) - 1u)) + carry;              // 0 .. 2^WB
+        carry = d > (1u << (WB - 1)) ? 1u : 0u;                    // digit = d - 2^WB * carry
+        d = (d - (carry << WB)) & 0xffffu;
+        if ((j & 1) == 0) packed[j >> 1] = d; else packed[j >> 1] |= d << 16;
+    }
+}
+
 }  // namespace zkp

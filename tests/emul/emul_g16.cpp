@@ -34,13 +34,13 @@ int emul_g16_witness_qap(int kind, uint64_t value, const uint64_t* set_vals, uin
     G16Lds L; L.base = lds.data(); L.m = T.m;
     g16_qap_proof(V, C, L, 0, 0, 1, NoSync());
     for (uint32_t k = 0; k < T.nv; k++) { fr x = ld_fr(z.data(), k, 0, 1); fp_to_raw(z_raw + 8 * k, x); }
-    // digits -> canonical value (sum d_j 1024^j), as 8 words
+    // digits -> canonical value (sum d_j 2^(WBITS j)), as 8 words
     auto undigit = [&](uint32_t idx, uint32_t* outw) {
         unsigned __int128 lo = 0, hi = 0;     // 260-bit accumulator as two halves: value = hi * 2^128 + lo (two's complement overall)
-        // Horner from the top digit: acc = acc * 1024 + d
+        // Horner from the top digit: acc = acc * 2^WBITS + d
         for (int j = (int)G16_NWIN - 1; j >= 0; j--) {
             const int32_t d = (int32_t)(int16_t)(sdig[(size_t)idx * G16_DIGW + (j >> 1)] >> (16 * (j & 1)));
-            hi = (hi << 10) | (lo >> 118); lo <<= 10;
+            hi = (hi << G16_WBITS) | (lo >> (128 - G16_WBITS)); lo <<= G16_WBITS;
             if (d >= 0) { const unsigned __int128 t = lo + (unsigned)d; if (t < lo) hi++; lo = t; }
             else { const unsigned __int128 t = lo - (unsigned)(-d); if (t > lo) hi--; lo = t; }
         }
@@ -69,11 +69,18 @@ int emul_g16_verify(int kind, const uint8_t* env, uint32_t len, const uint32_t* 
             g1_jac q = jac_from_aff(g1(ic + 16 * i));
             for (uint32_t w = 0; w < G16_NWIN; w++) {
                 g1_jac acc = q;
-                for (uint32_t e = 0; e < G16_NENT; e++) {
-                    g1_aff a; jac_to_aff(a, acc);
-                    uint32_t* dst = tab.data() + (((size_t)i * G16_NWIN + w) * G16_NENT + e) * 20;
-                    for (int k = 0; k < 10; k++) { dst[k] = a.x.v[k]; dst[10 + k] = a.y.v[k]; }
-                    acc = jac_add(acc, q);
+                for (uint32_t e0 = 0; e0 < G16_NENT; e0 += 8) {          // the device builder's batched conversion (k_g16_build_table)
+                    g1_jac pts[8]; fq zp[8];
+                    for (uint32_t k = 0; k < 8; k++) { pts[k] = acc; acc = jac_add(acc, q); zp[k] = k ? f_mul(zp[k - 1], pts[k].Z) : pts[k].Z; }
+                    fq inv = f_inv(zp[7]);
+                    for (int k = 7; k >= 0; k--) {
+                        const fq zi = k ? f_mul(inv, zp[k - 1]) : inv;
+                        if (k) inv = f_mul(inv, pts[k].Z);
+                        const fq zi2 = f_sq(zi);
+                        g1_aff a; a.x = f_mul(pts[k].X, zi2); a.y = f_mul(pts[k].Y, f_mul(zi2, zi));
+                        uint32_t* dst = tab.data() + (((size_t)i * G16_NWIN + w) * G16_NENT + e0 + k) * 20;
+                        for (int j = 0; j < 10; j++) { dst[j] = a.x.v[j]; dst[10 + j] = a.y.v[j]; }
+                    }
                 }
                 for (uint32_t k = 0; k < G16_WBITS; k++) q = jac_dbl(q);
             }
