@@ -15,7 +15,7 @@ proofs of all ranks are gathered to every rank with one RCCL all_gather inside t
 process_batch has to hand back.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
-  roofline       the dominant kernel of the mixed batch, k_msm_dma<G1Msm> (Groth16 key-point MSMs), against the HBM roof
+  roofline       the dominant kernel of the mixed batch, k_msm_gather<G1Msm> (Groth16 key-point MSMs), against the HBM roof
   roofline_valu  the same kernel against the VALU integer roof that actually binds it
   cpu_baseline   oracle/c's process_batch port (OpenMP over ops, like rayon) on a bounded sample of the same ops.
 """
@@ -34,9 +34,9 @@ sys.path.insert(0, ROOT)
 
 BATCH = 4096
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md
-FQ_MUL_PEAK_G = 128.5                    # G BN254-Fq products/s: 25.7 T v_mad_u64_u32/s measured (profiles/r02_fe_microbench.json) / 200 per product
-FQ_MUL_PER_G1_MADD = 11                  # 7M + 4S (madd-2007-bl)
-FE_MUL_PEAK_G = 257.0                    # G GF(2^255-19) products/s (100 v_mad_u64_u32 each), same microbenchmark
+MAD_ISSUE_T = 35.157                     # T v_mad_u64_u32 lane-ops/s, isolated issue-rate measurement (profiles/r02_fe_microbench.json)
+MADS_PER_G1_MADD = 7 * 200 + 4 * 155     # madd-2007-bl: 7 products of 200 mads, 4 squarings of 155 (bn254_fq.h)
+MADS_PER_ED_MADD = 7 * 100               # mixed addition with an affine-Niels entry: 7 GF(2^255-19) products of 100 mads
 ALGO_BYTES = {"range": 24 + 32 + 1478, "equality": 16 + 32 + 298, "membership16": 8 + 128 + 32 + 430}
 
 
@@ -230,7 +230,7 @@ def main():
         # launch its 598 B/proof ops; the steps alternate one of each, so the per-launch average is the mean of the two
         algo_launch = (ALGO_BYTES["equality"] * counts["equality"] + ALGO_BYTES["membership16"] * counts["membership"]) / 2.0
         achieved = algo_launch / (g1_avg_ms * 1e-3) / 1e9 if g1_avg_ms > 0 else 0.0
-        fq_rate = g1[2] * FQ_MUL_PER_G1_MADD / (g1[0] * 1e-3) / 1e9 if g1[0] > 0 else 0.0
+        g1_mad_rate = g1[2] * MADS_PER_G1_MADD / (g1[0] * 1e-3) / 1e12 if g1[0] > 0 else 0.0        # T mad/s
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         if os.path.exists(tpath):
@@ -250,18 +250,19 @@ def main():
             "ms_per_proof_p50": statistics.median(step_ms) / n,
             "ms_per_batch_p50": statistics.median(step_ms),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_msm_dma<G1Msm>",
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_msm_gather<G1Msm>",
                          "avg_launch_ms": g1_avg_ms, "launches": g1[1], "algorithmic_bytes_per_launch": algo_launch,
                          "share_of_step": g1[0] / (dt * 1e3) if world == 1 else None,
                          "note": "integer-ALU-bound kernel (SURVEY 8d): see roofline_valu; launch durations are taken on the kernel's own stream while the "
                                  "other variants' kernels share the GPU"},
-            "roofline_valu": {"bound": "valu-int", "achieved": fq_rate, "peak": FQ_MUL_PEAK_G, "unit": "G BN254-Fq products/s", "frac": fq_rate / FQ_MUL_PEAK_G,
-                              "kernel": "k_msm_dma<G1Msm>", "point_additions_per_step": g1[2] / max(1, args.steps),
-                              "peak_source": "profiles/r02_fe_microbench.json (v_mad_u64_u32 issue rate; 200 per lazily reduced Fq product)"},
+            "roofline_valu": {"bound": "valu-int", "achieved": g1_mad_rate, "peak": MAD_ISSUE_T, "unit": "T v_mad_u64_u32/s", "frac": g1_mad_rate / MAD_ISSUE_T,
+                              "kernel": "k_msm_gather<G1Msm>", "point_additions_per_step": g1[2] / max(1, args.steps), "mads_per_point_addition": MADS_PER_G1_MADD,
+                              "peak_source": "profiles/r02_fe_microbench.json: isolated v_mad_u64_u32 issue rate (the multiply-adds of the field products only; "
+                                             "carries, masks and loads share the same issue slots, a pure product chain reaches 73 % of it)"},
             "other_msm_kernels": {
-                "k_msm_dma<G2Msm>": {"avg_launch_ms": g2[0] / max(1, g2[1]), "launches": g2[1], "ms_per_step": g2[0] / max(1, args.steps)},
+                "k_msm_gather<G2Msm>": {"avg_launch_ms": g2[0] / max(1, g2[1]), "launches": g2[1], "ms_per_step": g2[0] / max(1, args.steps)},
                 "k_msm_dma<EdMsm>": {"avg_launch_ms": ed[0] / max(1, ed[1]), "launches": ed[1], "ms_per_step": ed[0] / max(1, args.steps),
-                                     "valu_frac": (ed[2] * 7 / (ed[0] * 1e-3) / 1e9 / FE_MUL_PEAK_G) if ed[0] > 0 else None}},
+                                     "valu_frac": (ed[2] * MADS_PER_ED_MADD / (ed[0] * 1e-3) / 1e12 / MAD_ISSUE_T) if ed[0] > 0 else None}},
         }
         res.update(extra)
         if not args.no_cpu_baseline:

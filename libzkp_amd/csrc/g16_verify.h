@@ -32,9 +32,12 @@ ZKP_HD inline bool fr_raw_lt_r(const uint32_t w[8]) {
     return false;
 }
 // ark-serialize uncompressed G1: x || y little-endian, flags in the top two bits of the last byte (bn254_g.h: g1_serialize).
-// Returns 0 invalid, 1 finite point, 2 point at infinity.
+// Returns 0 invalid, 1 finite point, 2 point at infinity.  Exactly ark's rules (SWFlags::from_u8 + deserialize_with_mode,
+// Compress::No, Validate::Yes): both flag bits set is an error; for a finite point the sign flag is NOT compared with y
+// (uncompressed deserialisation takes y from the bytes and ignores that bit); coordinates must be canonical and on the curve.
 ZKP_HD_NOINLINE inline int g1_from_ark(g1_aff& out, const uint8_t b[64]) {
     const uint32_t flags = b[63] & 0xC0u;
+    if (flags == 0xC0u) return 0;
     if (flags & 0x40u) return 2;
     uint32_t xw[8], yw[8];
     ld_le_words(xw, b); ld_le_words(yw, b + 32); yw[7] &= 0x3FFFFFFFu;
@@ -42,12 +45,12 @@ ZKP_HD_NOINLINE inline int g1_from_ark(g1_aff& out, const uint8_t b[64]) {
     out.x = fq_from_raw(xw); out.y = fq_from_raw(yw);
     const fq rhs = fq_add(fq_mul(fq_sq(out.x), out.x), fq_from_u64(3));
     if (!fq_eq(fq_sq(out.y), rhs)) return 0;
-    if (((flags & 0x80u) != 0) != fq_raw_gt_half(yw)) return 0;
     return 1;
 }
 // (the subgroup check of a finite point is g2_in_subgroup: the most expensive part, which the GPU path runs on a lane of its own)
 ZKP_HD_NOINLINE inline int g2_from_ark(g2_aff& out, const uint8_t b[128]) {
     const uint32_t flags = b[127] & 0xC0u;
+    if (flags == 0xC0u) return 0;
     if (flags & 0x40u) return 2;
     uint32_t w[4][8];
     for (int k = 0; k < 4; k++) ld_le_words(w[k], b + 32 * k);
@@ -56,9 +59,6 @@ ZKP_HD_NOINLINE inline int g2_from_ark(g2_aff& out, const uint8_t b[128]) {
     out.x = fq2{fq_from_raw(w[0]), fq_from_raw(w[1])}; out.y = fq2{fq_from_raw(w[2]), fq_from_raw(w[3])};
     const fq2 b2 = f_mul(fq2{fq_from_u64(3), fq_zero()}, f_inv(fq2{fq_from_u64(9), fq_from_u64(1)}));       // 3 / (9 + u)
     if (!fq2_eq(f_sq(out.y), f_add(f_mul(f_sq(out.x), out.x), b2))) return 0;
-    uint32_t nz = 0; for (int i = 0; i < 8; i++) nz |= w[3][i];
-    const bool larger = nz ? fq_raw_gt_half(w[3]) : fq_raw_gt_half(w[2]);
-    if (((flags & 0x80u) != 0) != larger) return 0;
     return 1;
 }
 // G2 has a cofactor: r * Q must be the identity

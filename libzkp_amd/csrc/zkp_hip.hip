@@ -288,6 +288,16 @@ void dev_scope_quiesce() { if (dev().stream) (void)hipStreamSynchronize(dev().st
 uint32_t g_budget_request = 0;     // 0 = choose per launch
 double g_fill = 1.0;               // benchmarking knob: scales the resident-workgroup count the Bulletproofs MSM chunking aims at
 uint32_t g_subbatches = 1;         // >1: independent slices on separate streams (measured slower on MI355X: see DESIGN.md)
+// Stream priorities (mixed batches run their variants on separate streams).  0 = greatest priority of the device, 1 = default,
+// 2 = least.  The Bulletproofs pipeline is a chain of ~80 dependent launches, most of them short: it gets the greatest priority
+// so that each of its kernels starts as soon as workgroup slots free up, while the long Groth16 MSM grids take the least.
+int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
+int stream_priority(int level) {
+    int least = 0, greatest = 0; (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    return level == 0 ? greatest : level == 2 ? least : (least + greatest) / 2;
+}
+int bp_priority_level() { static const int v = env_int("ZKP_HIP_BP_PRIORITY", 0); return v; }
+int g16_priority_level() { static const int v = env_int("ZKP_HIP_G16_PRIORITY", 2); return v; }
 
 int prof_begin(Device::KProf& K, hipStream_t st, hipEvent_t* e1) {
     *e1 = nullptr;
@@ -433,8 +443,8 @@ int init_device() {
     D.nsub = ns;
     D.sub.resize((size_t)NSLOTS * ns);
     for (auto& sb : D.sub) {
-        HIP_TRY(hipStreamCreateWithFlags(&sb.stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&sb.side, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithPriority(&sb.stream, hipStreamNonBlocking, stream_priority(bp_priority_level())));
+        HIP_TRY(hipStreamCreateWithPriority(&sb.side, hipStreamNonBlocking, stream_priority(bp_priority_level())));
         HIP_TRY(hipEventCreateWithFlags(&sb.start, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sb.done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sb.side_go, hipEventDisableTiming));

@@ -306,16 +306,18 @@ def ser_g2(pt):
 
 
 def de_g1(b):
+    """ark-serialize, Compress::No, Validate::Yes: both flag bits set is an error (SWFlags::from_u8); the sign flag of a
+    finite point is ignored (y comes from the bytes); canonical coordinates, on the curve (G1 has cofactor 1)."""
     if len(b) != 64:
         return False, None
     flags = b[63] & 0xC0
+    if flags == 0xC0:
+        return False, None
     if flags & 0x40:
         return True, None
     x = int.from_bytes(b[:32], "little")
     y = int.from_bytes(b[32:63] + bytes([b[63] & 0x3F]), "little")
     if x >= P or y >= P or not G1C.is_on_curve((x, y)):
-        return False, None
-    if bool(flags & 0x80) != (y > (-y) % P):
         return False, None
     return True, (x, y)
 
@@ -324,6 +326,8 @@ def de_g2(b):
     if len(b) != 128:
         return False, None
     flags = b[127] & 0xC0
+    if flags == 0xC0:
+        return False, None
     if flags & 0x40:
         return True, None
     v = [int.from_bytes(b[32 * i: 32 * i + 32], "little") for i in range(3)]
@@ -332,7 +336,5 @@ def de_g2(b):
         return False, None
     pt = ((v[0], v[1]), (v[2], v[3]))
     if not G2C.is_on_curve(pt) or G2C.mul_pt(pt, R, reduce=False) is not None:     # subgroup check (G2 has a cofactor)
-        return False, None
-    if bool(flags & 0x80) != _f2_gt(pt[1], f2_neg(pt[1])):
         return False, None
     return True, pt

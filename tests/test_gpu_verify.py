@@ -181,11 +181,26 @@ def test_groth16_verification(hip):
     assert z.verify_equality_with_commitment_batch(proofs, [z.snark_commit_value(v) for v in vals]) == [True] * 24
     assert not z.verify_equality(proofs[0], vals[0], vals[0] + 1) and not z.verify_equality(proofs[0], vals[1], vals[1])
     bad = []
+    sign_bits = {(73, 7), (201, 7), (265, 7)}                # the sign flags of A, B, C: ignored for uncompressed points (below)
     for p in proofs:
-        b = bytearray(p); b[int(rng.integers(0, 298))] ^= 1 << int(rng.integers(0, 8)); bad.append(bytes(b))
+        while True:
+            pos, bit = int(rng.integers(0, 298)), int(rng.integers(0, 8))
+            if (pos, bit) not in sign_bits:
+                break
+        b = bytearray(p); b[pos] ^= 1 << bit; bad.append(bytes(b))
     want = [g.verify_equality_with_commitment(b, b[266:], SS) for b in bad[:8]]
     got = api._verify_snark_envelopes(0, bad)
     assert got[:8] == want and not any(got)
+    # ark-serialize's parsing rules on malleated encodings (snark.rs:378 -> Proof::deserialize_uncompressed): the sign flag of an
+    # uncompressed finite point is ignored, so flipping it leaves the proof valid; both flag bits set is a deserialisation error
+    mall = []
+    for last in (73, 201, 265):
+        b = bytearray(proofs[0]); b[last] ^= 0x80; mall.append(bytes(b))
+    for last in (73, 201, 265):
+        b = bytearray(proofs[0]); b[last] |= 0xC0; mall.append(bytes(b))
+    want = [g.verify_equality_with_commitment(b, b[266:], SS) for b in mall]
+    assert want == [True, True, True, False, False, False]
+    assert api._verify_snark_envelopes(0, mall) == want
     sets = [[int(x) for x in rng.choice(2**32, 5, replace=False)] for _ in range(6)]
     mp = z.prove_membership_batch([s[i % 5] for i, s in enumerate(sets)], sets, seeds=seeds[:32 * 6])
     assert z.verify_membership_batch(mp, sets) == [True] * 6
