@@ -73,6 +73,29 @@ ZKP_HD inline fq fq_sq(const fq& a) {
     return r;
 }
 
+// (a * b + c * d) / 2^260 mod p with ONE Montgomery reduction: both products are accumulated into the same columns (200 limb
+// products), then reduced once (100) -- 300 multiply-adds where two fq_mul and an addition take 400.  Inputs: limbs < 2^28
+// each (column sums of 20 products of < 2^56 plus the reduction terms stay below 2^61); output carried, value < (A*B + C*D) /
+// (84.6 p) + p.
+ZKP_HD inline fq fq_mul_add2(const fq& a, const fq& b, const fq& c, const fq& d) {
+    uint32_t m[10]; fq r; uint64_t acc = 0;
+    ZKP_UNROLL for (int i = 0; i < 10; i++) {
+        ZKP_UNROLL for (int j = 0; j <= i; j++) { acc += (uint64_t)a.v[j] * b.v[i - j]; acc += (uint64_t)c.v[j] * d.v[i - j]; }
+        ZKP_UNROLL for (int j = 0; j < i; j++) acc += (uint64_t)m[j] * fq_pl(i - j);
+        m[i] = ((uint32_t)acc * ZKP_FQ_N0) & ZKP_FQ_MASK;
+        acc += (uint64_t)m[i] * fq_pl(0);
+        acc >>= 26;
+    }
+    ZKP_UNROLL for (int i = 10; i < 19; i++) {
+        ZKP_UNROLL for (int j = i - 9; j < 10; j++) { acc += (uint64_t)a.v[j] * b.v[i - j]; acc += (uint64_t)c.v[j] * d.v[i - j]; }
+        ZKP_UNROLL for (int j = i - 9; j < 10; j++) acc += (uint64_t)m[j] * fq_pl(i - j);
+        r.v[i - 10] = (uint32_t)acc & ZKP_FQ_MASK;
+        acc >>= 26;
+    }
+    r.v[9] = (uint32_t)acc;
+    return r;
+}
+
 // limb-wise (lazy) operations
 ZKP_HD inline fq fq_add_l(const fq& a, const fq& b) { fq r; ZKP_UNROLL for (int i = 0; i < 10; i++) r.v[i] = a.v[i] + b.v[i]; return r; }
 ZKP_HD inline fq fq_dbl_l(const fq& a) { fq r; ZKP_UNROLL for (int i = 0; i < 10; i++) r.v[i] = a.v[i] << 1; return r; }

@@ -293,7 +293,12 @@ ZKP_HD inline void step_vtranscript(const VfyView& V, uint32_t job, Strobe& s) {
         ld_bytes_words(w, pr + 224 + 64 * j + 32, 8); merlin_append_words(s, "R", 1, w, 8);
         u[j] = merlin_challenge_scalar(s, "u", 1);
     }
-    const sc c = merlin_challenge_scalar(s, "libzkp-amd batch weight", 23);   // folds the two equations; not part of the proof
+    // The weight that folds the two verification equations (upstream draws it from an RNG seeded outside the proof) is derived
+    // only after EVERYTHING the prover sent has been absorbed -- including the inner-product argument's final scalars a and b,
+    // which the proof transcript itself never absorbs -- so no part of the proof can be chosen with knowledge of it.
+    merlin_append_scalar(s, "a", 1, r_a);
+    merlin_append_scalar(s, "b", 1, r_b);
+    const sc c = merlin_challenge_scalar(s, "libzkp-amd batch weight", 23);   // verifier-internal: not part of the proof
     // one inversion for y, u_0..u_{lg-1} (Montgomery's trick)
     sc pre[7]; sc run = y;
     pre[0] = sc_one();

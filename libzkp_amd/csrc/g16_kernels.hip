@@ -8,14 +8,24 @@ struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b
     static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int16_t)(word >> (16 * (w & 1u))); }
     using Acc = g1_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq>(); }
-    static constexpr uint32_t GATHER_WAVES = 3; static constexpr bool GATHER_PREFETCH = true;      // k_msm_gather: 3 waves/SIMD, entries one step ahead
-    static __device__ __forceinline__ Acc accumulate_entry(const Acc& acc, int32_t d, const uint32_t* e) {
+#ifndef ZKP_G1_GATHER_WAVES
+#define ZKP_G1_GATHER_WAVES 3
+#define ZKP_G1_GATHER_PREFETCH 1
+#endif
+    static constexpr uint32_t GATHER_WAVES = ZKP_G1_GATHER_WAVES; static constexpr bool GATHER_PREFETCH = ZKP_G1_GATHER_PREFETCH != 0;      // k_msm_gather: 3 waves/SIMD, entries one step ahead
+    using GAcc = g1_xyzz;                                         // the gather loop accumulates in XYZZ coordinates (bn254_g.h)
+    static __device__ __forceinline__ GAcc to_gather(const g1_jac& a) { return xyzz_from_jac(a); }
+    static __device__ __forceinline__ g1_jac from_gather(const GAcc& a) { return jac_from_xyzz(a); }
+    static __device__ __forceinline__ GAcc accumulate_entry(const GAcc& acc, int32_t d, const uint32_t* e) {
         g1_aff q; ZKP_UNROLL for (int k = 0; k < 10; k++) { q.x.v[k] = e[k]; q.y.v[k] = e[10 + k]; }
         q.y = fq_select(d < 0, fq_sub_k4(fq_zero(), q.y), q.y);          // 4p - y: limbs < 2^27, fine as a product operand
-        return g1_madd_lazy(acc, q);
+        return g1_mmadd_lazy(acc, q);
     }
-    static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
-        return accumulate_entry(acc, d, subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W);
+    static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {      // LDS A/B build
+        const uint32_t* e = subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W;
+        g1_aff q; ZKP_UNROLL for (int k = 0; k < 10; k++) { q.x.v[k] = e[k]; q.y.v[k] = e[10 + k]; }
+        q.y = fq_select(d < 0, fq_sub_k4(fq_zero(), q.y), q.y);
+        return g1_madd_lazy(acc, q);
     }
     static __device__ __forceinline__ void store(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const Acc& a) { st_g1_jac(p, idx, row, rows, a); }
     static __device__ __forceinline__ Acc load(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) { return ld_g1_jac(p, idx, row, rows); }
@@ -28,6 +38,9 @@ struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
     using Acc = g2_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq2>(); }
     static constexpr uint32_t GATHER_WAVES = 2; static constexpr bool GATHER_PREFETCH = false;     // k_msm_gather: 256 VGPRs are taken by the addition itself
+    using GAcc = g2_jac;
+    static __device__ __forceinline__ GAcc to_gather(const g2_jac& a) { return a; }
+    static __device__ __forceinline__ g2_jac from_gather(const GAcc& a) { return a; }
     static __device__ __forceinline__ Acc accumulate_entry(const Acc& acc, int32_t d, const uint32_t* e) {
         g2_aff q; ZKP_UNROLL for (int k = 0; k < 10; k++) { q.x.c0.v[k] = e[k]; q.x.c1.v[k] = e[10 + k]; q.y.c0.v[k] = e[20 + k]; q.y.c1.v[k] = e[30 + k]; }
         return g2_madd_lazy(acc, q, d < 0);
@@ -52,10 +65,13 @@ __global__ void __launch_bounds__(TB) k_g16_zdigits(G16View V) {
 }
 struct DevSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
 // one workgroup = one proof; the three polynomials (a, b, c evaluations -> h) live in LDS, word-major
-__global__ void __launch_bounds__(TB) k_g16_qap(G16View V, G16Circuit C) {
+// 512 lanes: the 96 KB LDS image of a membership proof allows one workgroup per CU, so the workgroup itself has to bring the
+// waves (2 per SIMD) that hide the LDS latency of the butterfly stages
+static constexpr int QAP_TB = 512;
+__global__ void __launch_bounds__(QAP_TB) k_g16_qap(G16View V, G16Circuit C) {
     extern __shared__ uint32_t g16_lds[];
     G16Lds L; L.base = g16_lds; L.m = C.m;
-    g16_qap_proof(V, C, L, blockIdx.x, threadIdx.x, TB, DevSync());
+    g16_qap_proof(V, C, L, blockIdx.x, threadIdx.x, QAP_TB, DevSync());
 }
 __global__ void __launch_bounds__(TW) k_g16_cparts(G16View V, const uint32_t* sum_g1, uint32_t* tmp_g1) {
     const uint32_t row = blockIdx.x * TW + threadIdx.x;
@@ -138,7 +154,7 @@ hipError_t g16_launch_qap(const G16View& V, const G16Circuit& C, hipStream_t st)
     const size_t lds = (size_t)3 * 8 * C.m * 4;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_g16_qap), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    k_g16_qap<<<V.rows, TB, lds, st>>>(V, C);
+    k_g16_qap<<<V.rows, QAP_TB, lds, st>>>(V, C);
     return hipSuccess;
 }
 void g16_launch_cparts(const G16View& V, const uint32_t* sum_g1, uint32_t* tmp_g1, hipStream_t st) {

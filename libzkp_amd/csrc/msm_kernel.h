@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
     const uint32_t row = group * 256u + tid;
     const bool active = row < m.rows;
     uint32_t s = m.chunk_begin[chunk], w = m.chunk_win0[chunk], left = m.chunk_nwin[chunk];
-    typename T::Acc acc = m.acc_init ? T::load(m.acc_init, 0, 0, 1) : T::identity();
+    typename T::GAcc acc = T::to_gather(m.acc_init ? T::load(m.acc_init, 0, 0, 1) : T::identity());    // the coordinate system of the loop
     const uint4* const table4 = reinterpret_cast<const uint4*>(m.table);
     auto digit_word = [&](uint32_t slot, uint32_t win) -> uint32_t {
         const uint32_t srow = m.slot_scalar ? m.slot_scalar[slot] : slot;
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
         const uint4* src = table4 + (((size_t)m.slot_base[slot] * T::NWIN + win) * T::NENT + (uint32_t)((d < 0 ? -d : d) - 1)) * V4;
         ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) e[k] = src[k];
     };
-    if (left == 0) { if (active) T::store(m.partial, chunk, row, m.rows, acc); return; }
+    if (left == 0) { if (active) T::store(m.partial, chunk, row, m.rows, T::from_gather(acc)); return; }
     uint32_t dw = digit_word(s, w);                               // the chunk may start in the middle of a word
     int32_t d = T::digit(dw, w);
     uint4 cur[V4], nxt[V4];
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
         }
         s = ns; w = nw; d = dn; left--;
     }
-    if (active) T::store(m.partial, chunk, row, m.rows, acc);
+    if (active) T::store(m.partial, chunk, row, m.rows, T::from_gather(acc));
 }
 
 // Partial sums of one target: a block owns 64 consecutive rows, its 8 waves each add every 8th chunk partial for those

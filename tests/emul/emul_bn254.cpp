@@ -44,6 +44,16 @@ void emul_g1_lazy_chain(const uint32_t o[16], const uint32_t* pts, const int* si
     }
     g1_serialize(out, acc);
 }
+// the same chain in the XYZZ coordinates of k_msm_gather<G1Msm>: Jacobian -> XYZZ -> additions -> Jacobian
+void emul_g1_xyzz_chain(const uint32_t o[16], const uint32_t* pts, const int* signs, int n, uint32_t out[16]) {
+    g1_xyzz acc = xyzz_from_jac(jac_dbl(jac_from_aff(load_g1(o))));
+    for (int i = 0; i < n; i++) {
+        g1_aff q = load_g1(pts + 16 * i);
+        q.y = fq_select(signs[i] < 0, fq_sub_k4(fq_zero(), q.y), q.y);
+        acc = g1_mmadd_lazy(acc, q);
+    }
+    g1_serialize(out, jac_from_xyzz(acc));
+}
 void emul_g2_lazy_chain(const uint32_t o[32], const uint32_t* pts, const int* signs, int n, uint32_t out[32]) {
     g2_jac acc = jac_dbl(jac_from_aff(load_g2(o)));
     for (int i = 0; i < n; i++) {

@@ -106,6 +106,8 @@ def test_msm_inner_loop_lazy(libs):
     pts1 = (ctypes.c_uint32 * (16 * n))(*sum((g1w(b.G1C.mul_pt(b.G1, k)) for k in ks), []))
     lib.emul_g1_lazy_chain((ctypes.c_uint32 * 16)(*g1w(b.G1C.mul_pt(b.G1, ko))), pts1, arr, n, o16)
     assert I(o16).to_bytes(64, "little") == b.ser_g1(b.G1C.mul_pt(b.G1, total))
+    lib.emul_g1_xyzz_chain((ctypes.c_uint32 * 16)(*g1w(b.G1C.mul_pt(b.G1, ko))), pts1, arr, n, o16)          # the XYZZ accumulator of the gather kernel
+    assert I(o16).to_bytes(64, "little") == b.ser_g1(b.G1C.mul_pt(b.G1, total))
     pts2 = (ctypes.c_uint32 * (32 * n))(*sum((g2w(b.G2C.mul_pt(b.G2, k)) for k in ks), []))
     lib.emul_g2_lazy_chain((ctypes.c_uint32 * 32)(*g2w(b.G2C.mul_pt(b.G2, ko))), pts2, arr, n, o32)
     assert I(o32).to_bytes(128, "little") == b.ser_g2(b.G2C.mul_pt(b.G2, total))

@@ -122,6 +122,41 @@ def test_g1_madd_lazy_is_closed_over_safe_inputs():
         assert all(o.val <= 3000 and max(o.l[:9]) <= M26 for o in out)
 
 
+def mul_add2(a, b, c, d):
+    """fq_mul_add2: both products in the same columns, one reduction"""
+    for col in range(19):
+        acc = sum(a.l[j] * b.l[col - j] + c.l[j] * d.l[col - j] for j in range(10) if 0 <= col - j < 10)
+        acc += sum(M26 * PL[col - j] for j in range(10) if 0 <= col - j < 10)
+        assert acc + (1 << 38) < 1 << 64, ("column", col, acc.bit_length())
+    out = (a.val * b.val + c.val * d.val) // R_OVER_P + 1000 + 1
+    assert out < 4000, "product leaves the safe range"
+    return carried(out)
+
+
+def g1_mmadd_lazy(X1, Y1, ZZ1, ZZZ1, x2, y2):
+    U2, S2 = mul(x2, ZZ1), mul(y2, ZZZ1)
+    Pv, Rv = sub_k(4, U2, X1), sub_k(4, S2, Y1)
+    PP = sq(Pv)
+    PPP, Q = mul(Pv, PP), mul(X1, PP)
+    RR = sq(Rv)
+    X3 = reduce_weak(sub_k(8, sub_k(4, RR, PPP), dbl_l(Q)))
+    zero = V([0] * 10, 0)
+    Y3 = mul_add2(Rv, sub_k(4, Q, X3), sub_k(4, zero, Y1), PPP)
+    return X3, Y3, mul(ZZ1, PP), mul(ZZZ1, PPP)
+
+
+def test_g1_mmadd_lazy_is_closed_over_safe_inputs():
+    """the XYZZ accumulator of k_msm_gather<G1Msm>: every coordinate handed to the next iteration is safe again, and so are the
+    coordinates of the Jacobian point it is converted to at the end of a chunk"""
+    zero = V([0] * 10, 0)
+    neg_y = sub_k(4, zero, CANON)
+    for y2 in (CANON, neg_y):
+        out = g1_mmadd_lazy(SAFE, SAFE, SAFE, SAFE, CANON, y2)
+        assert all(o.val <= 3000 and max(o.l[:9]) <= M26 for o in out)
+    reduce_weak(mul(SAFE, SAFE)); reduce_weak(SAFE)                      # jac_from_xyzz
+    sq(SAFE); mul(sq(SAFE), SAFE)                                        # xyzz_from_jac
+
+
 def kara(a, b):
     return mul(a[0], b[0]), mul(a[1], b[1]), mul(add_l(a[0], a[1]), add_l(b[0], b[1]))
 
