@@ -203,6 +203,11 @@ int zkp_hip_plan_shards(uint64_t n, const zkp_hip_op* ops, uint32_t shards, uint
 typedef struct zkp_hip_batch zkp_hip_batch;
 int zkp_hip_batch_stage(uint64_t n, const zkp_hip_op* ops, const uint64_t* lists, const uint8_t* seeds, zkp_hip_batch** batch);
 int zkp_hip_batch_prove(zkp_hip_batch* batch);
+/* The same in two halves: _async enqueues the whole proving on every shard and returns; _wait blocks until it is done (fetch and
+ * device_results wait by themselves).  A shard keeps two lanes of streams and workspaces, so a caller that stages batch k + 1 and
+ * launches it before waiting for batch k has two batches in flight: the latency-bound tail of one runs under the MSMs of the next. */
+int zkp_hip_batch_prove_async(zkp_hip_batch* batch);
+int zkp_hip_batch_wait(zkp_hip_batch* batch);
 uint64_t zkp_hip_batch_max_bytes(const zkp_hip_batch* batch);
 int zkp_hip_batch_fetch(zkp_hip_batch* batch, uint8_t* out, uint64_t out_cap, uint64_t* out_off, int32_t* status);
 /* Device-resident results of a proved batch, shard by shard (a multi-process driver gathers them with RCCL instead of going

@@ -19,7 +19,7 @@ EXPORTS = (
     "zkp_hip_prove_improvement_batch_device", "zkp_hip_verify_range_batch", "zkp_hip_verify_threshold_batch", "zkp_hip_verify_consistency_batch", "zkp_hip_verify_equality_batch", "zkp_hip_verify_membership_batch",
     "zkp_hip_verify_improvement_batch", "zkp_hip_process_batch", "zkp_hip_profile_enable", "zkp_hip_profile_read", "zkp_hip_set_window_budget", "zkp_hip_set_subbatches", "zkp_hip_set_msm_variant",
     "zkp_hip_init_devices", "zkp_hip_device_count", "zkp_hip_use_device", "zkp_hip_process_batch_bytes", "zkp_hip_batch_stage", "zkp_hip_batch_prove", "zkp_hip_batch_max_bytes",
-    "zkp_hip_batch_fetch", "zkp_hip_batch_free", "zkp_hip_profile_read_kernel", "zkp_hip_batch_device_results", "zkp_hip_plan_shards",
+    "zkp_hip_batch_fetch", "zkp_hip_batch_free", "zkp_hip_profile_read_kernel", "zkp_hip_batch_device_results", "zkp_hip_plan_shards", "zkp_hip_batch_prove_async", "zkp_hip_batch_wait",
 )
 
 _lib = None
@@ -128,8 +128,9 @@ def lib():
         L.zkp_hip_process_batch_bytes.restype = ctypes.c_int
         L.zkp_hip_batch_stage.argtypes = [u64, vp, vp, vp, ctypes.POINTER(vp)]
         L.zkp_hip_batch_stage.restype = ctypes.c_int
-        L.zkp_hip_batch_prove.argtypes = [vp]
-        L.zkp_hip_batch_prove.restype = ctypes.c_int
+        for f in (L.zkp_hip_batch_prove, L.zkp_hip_batch_prove_async, L.zkp_hip_batch_wait):
+            f.argtypes = [vp]
+            f.restype = ctypes.c_int
         L.zkp_hip_batch_max_bytes.argtypes = [vp]
         L.zkp_hip_batch_max_bytes.restype = u64
         L.zkp_hip_batch_fetch.argtypes = [vp, vp, u64, vp, vp]

@@ -641,6 +641,7 @@ int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_
         w.V.seeds = reinterpret_cast<const uint32_t*>(d_seeds + 32 * lo); w.T.seeds = w.V.seeds;
         w.V.out = d_out + lo * stride;
         HIP_TRY(hipStreamWaitEvent(sb.stream, first.start, 0));        // (the slot's previous batch is ahead of this one on sb.stream)
+        if (sb.used) HIP_TRY(hipStreamWaitEvent(sb.stream, sb.done, 0));   // ... unless it was a host-described job list on another stream (run_jobs_on)
         k_build_range<<<(C + TB - 1) / TB, TB, 0, sb.stream>>>(w.J, C, d_value + lo, d_min + lo, d_max + lo, lg, w.V.out, stride, d_out_len + lo, d_status + lo);
         if ((rc = run_pipeline(w, M, C, sb.stream, sb))) return rc;
         HIP_TRY(hipEventRecord(sb.done, sb.stream)); sb.used = true;

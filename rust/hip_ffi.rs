@@ -97,6 +97,8 @@ extern "C" {
     pub fn zkp_hip_plan_shards(n: u64, ops: *const zkp_hip_op, shards: u32, shard_of_op: *mut u32) -> c_int;
     pub fn zkp_hip_batch_stage(n: u64, ops: *const zkp_hip_op, lists: *const u64, seeds: *const u8, batch: *mut *mut zkp_hip_batch) -> c_int;
     pub fn zkp_hip_batch_prove(batch: *mut zkp_hip_batch) -> c_int;
+    pub fn zkp_hip_batch_prove_async(batch: *mut zkp_hip_batch) -> c_int;
+    pub fn zkp_hip_batch_wait(batch: *mut zkp_hip_batch) -> c_int;
     pub fn zkp_hip_batch_max_bytes(batch: *const zkp_hip_batch) -> u64;
     pub fn zkp_hip_batch_fetch(batch: *mut zkp_hip_batch, out: *mut u8, out_cap: u64, out_off: *mut u64, status: *mut i32) -> c_int;
     pub fn zkp_hip_batch_device_results(batch: *mut zkp_hip_batch, shard: u32, d_out: *mut u8, cap: u64, d_out_off: *mut u64, n_ops: *mut u64,

@@ -142,6 +142,15 @@ int main(int argc, char** argv) {
     CHECK(zkp_hip_batch_stage(6, ops.data(), lists.data(), bs.data(), &B) == 0 && B != nullptr); CALLED(zkp_hip_batch_stage);
     CHECK(zkp_hip_batch_max_bytes(B) == cap); CALLED(zkp_hip_batch_max_bytes);
     CHECK(zkp_hip_batch_prove(B) == 0); CALLED(zkp_hip_batch_prove);
+    {   // two batches in flight on the shard's two lanes: same bytes as the blocking call
+        zkp_hip_batch* B2 = nullptr;
+        CHECK(zkp_hip_batch_stage(6, ops.data(), lists.data(), bs.data(), &B2) == 0);
+        CHECK(zkp_hip_batch_prove_async(B) == 0 && zkp_hip_batch_prove_async(B2) == 0); CALLED(zkp_hip_batch_prove_async);
+        CHECK(zkp_hip_batch_wait(B2) == 0 && zkp_hip_batch_wait(B) == 0); CALLED(zkp_hip_batch_wait);
+        std::vector<uint8_t> o2(cap); std::vector<uint64_t> f2(7); std::vector<int32_t> s2(6);
+        CHECK(zkp_hip_batch_fetch(B2, o2.data(), cap, f2.data(), s2.data()) == 0 && f2 == off && std::memcmp(o2.data(), out.data(), off[6]) == 0);
+        zkp_hip_batch_free(B2);
+    }
     std::vector<uint8_t> out2(cap); std::vector<uint64_t> off2(7); std::vector<int32_t> st2(6);
     CHECK(zkp_hip_batch_fetch(B, out2.data(), cap, off2.data(), st2.data()) == 0 && off2 == off && std::memcmp(out.data(), out2.data(), off[6]) == 0); CALLED(zkp_hip_batch_fetch);
     {
@@ -171,7 +180,7 @@ int main(int argc, char** argv) {
     zkp_hip_shutdown();
     CHECK(zkp_hip_device_count() == 0);
 
-    const size_t expected = 42;                                  // declarations in include/libzkp_hip.h (tests/test_abi.py counts them too)
+    const size_t expected = 44;                                  // declarations in include/libzkp_hip.h (tests/test_abi.py counts them too)
     if (called.size() != expected) { std::fprintf(stderr, "called %zu of %zu entry points\n", called.size(), expected); failures++; }
     if (failures) { std::fprintf(stderr, "abi_call_all: %d failure(s)\n", failures); return 1; }
     std::printf("abi_call_all ok: %zu symbols\n", called.size());

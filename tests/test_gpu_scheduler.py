@@ -228,3 +228,28 @@ def test_two_shards_on_one_gpu_reproduce_single_shard_bytes():
     finally:
         L.zkp_hip_shutdown()
         _lib()
+
+
+def test_two_batches_in_flight_on_one_shard():
+    """zkp_hip_batch_prove_async / _wait: two staged batches on the shard's two lanes of streams, launched before either is
+    waited for, several rounds; bytes equal the blocking calls (workspaces of a lane are reused stream-ordered)."""
+    from libzkp_amd import _native
+    L = _lib()
+    batches = [wl.mixed_ops(160, 31), _six_kind_batch(96, 7), wl.mixed_ops(64, 32)]
+    want = [_run(L, *b) for b in batches]
+    hs = []
+    for b in batches:
+        h = ctypes.c_void_p()
+        assert L.zkp_hip_batch_stage(len(b[0]), P(b[0]), P(b[1]), P(b[2]), ctypes.byref(h)) == 0, _native.last_error()
+        hs.append(h)
+    for rnd in range(3):
+        for h in hs:
+            assert L.zkp_hip_batch_prove_async(h) == 0, _native.last_error()
+        for h in reversed(hs):
+            assert L.zkp_hip_batch_wait(h) == 0
+    for h, b, (rc, got, st, off) in zip(hs, batches, want):
+        n = len(b[0]); cap = int(L.zkp_hip_batch_max_bytes(h))
+        out = np.zeros(cap, dtype=np.uint8); o2 = np.zeros(n + 1, dtype=np.uint64); s2 = np.zeros(n, dtype=np.int32)
+        assert L.zkp_hip_batch_fetch(h, P(out), cap, P(o2), P(s2)) == rc
+        assert (o2 == off).all() and (s2 == st).all() and out[:int(o2[-1])].tobytes() == b"".join(got)
+        L.zkp_hip_batch_free(h)
