@@ -22,6 +22,27 @@ enum { VP_V = 0, VP_A, VP_S, VP_T1, VP_T2, VP_L = 5, VP_R = 11, VP_NUM = 17 };
 enum { VS_Z = 0, VS_ZZ, VS_YINV, VS_A, VS_B, VS_U = 5, VS_UINV = 11, VS_NUM = 17 };
 constexpr int32_t VFY_UNSUPPORTED = 2;      // reserved verdict (every bit width the reference accepts -- 8, 16, 32, 64 -- is verified)
 
+// Batch check (bpv_kernels.hip: k_rlc_*): the 17 M weighted proof-point terms go through ONE bucket-method MSM with signed
+// radix-2048 digits: 24 windows of 1024 buckets.
+constexpr uint32_t RLC_MIN_JOBS = 4096;      // measured break-even ~2100 jobs (profiles/r02_verify_rates.json); ZKP_HIP_BATCH_VERIFY_MIN overrides
+// Window width 11: 23 windows cover the 253 bits of a scalar < l ~ 2^252 exactly, so every window's digits are uniform over the
+// 1024 bucket magnitudes (a width that leaves a short top window puts half of all points into one or two buckets there); the
+// 24th window only ever holds the recoding carry.
+constexpr uint32_t RLC_WBITS = 11, RLC_NWIN = 24, RLC_NBUCKET = 1u << (RLC_WBITS - 1), RLC_SEG = 32, RLC_NSEG = RLC_NBUCKET / RLC_SEG, RLC_NIELS_W = 32;
+struct RlcView {
+    uint32_t N;                   // 17 * M point terms, index = p * M + job
+    uint32_t* niels;              // [N][32] affine-Niels form of the decoded points (30 words used)
+    int16_t* dig;                 // [NWIN][N] signed digits of the weighted scalars
+    uint32_t* count;              // [NWIN][NBUCKET + 1] points per bucket magnitude (index 0 unused)
+    uint32_t* start;              // [NWIN][NBUCKET + 2] exclusive prefix sums
+    uint32_t* cursor;             // [NWIN][NBUCKET + 1] scatter cursors
+    uint32_t* sorted;             // [NWIN][N] point index | sign << 31, grouped by bucket
+    uint32_t* bucket;             // [NWIN * NBUCKET][40] bucket sums (extended coordinates, word-major per point)
+    uint32_t* seg;                // [NWIN * NSEG][40]
+    const uint32_t* fixed_sum;    // [40] the generator part (one-row fixed-base MSM of the summed coefficients)
+    uint32_t* result;             // [8] ristretto encoding of the whole combination, [8] = 1 iff it is the identity
+};
+
 struct VfyView {
     uint32_t M;                   // jobs
     const uint8_t* in;            // the envelopes
@@ -37,6 +58,11 @@ struct VfyView {
     uint32_t* partial;            // the MSM partial array; proof-point products go to chunks var_chunk0 + p
     uint32_t var_chunk0;
     const uint32_t* table;        // generator tables (parse step: min*B, max*B)
+    // batch mode (random linear combination over the whole batch): rho = [8][M] per-job weights (Montgomery scalars), or
+    // null for the per-job check.  With weights every coefficient is multiplied by rho_job; the generator coefficients then go to
+    // fterm ([130][8][M] Montgomery scalars, summed over the jobs afterwards) instead of per-job digit rows.
+    const uint32_t* rho;
+    uint32_t* fterm;
     // consistency proofs: a variable number of jobs per envelope
     const uint32_t* job_base;     // [n + 1] first job of each envelope (host: k - 1 jobs where the framing can hold k commitments)
     int32_t* env_bad;             // [n] envelope-level verdict of the framing / commitment checks
@@ -254,6 +280,16 @@ ZKP_HD inline void step_vdecode(const VfyView& V, uint32_t p, uint32_t job) {
     st_ge(V.pts, p, job, V.M, pt);
 }
 
+// coefficient of generator `base` for this job: per-job digits, or the weighted term of the batch check
+ZKP_HD inline void st_gen_coef(const VfyView& V, uint32_t base, uint32_t job, const sc& coef) {
+    if (V.rho == nullptr) st_digits(V.digits, base, job, V.M, coef);
+    else st_sc(V.fterm, base, job, V.M, sc_mul(coef, ld_sc(V.rho, 0, job, V.M)));
+}
+// raw scalar of proof point p (weighted in batch mode)
+ZKP_HD inline void st_point_scalar(const VfyView& V, uint32_t p, uint32_t job, const sc& mont) {
+    st_sc(V.vscal, p, job, V.M, sc_to_raw(V.rho == nullptr ? mont : sc_mul(mont, ld_sc(V.rho, 0, job, V.M))));
+}
+
 // ---- step 2: transcript replay, job-level scalars.  thread = job
 ZKP_HD inline void step_vtranscript(const VfyView& V, uint32_t job, Strobe& s) {
     if (V.bad[job]) return;
@@ -316,18 +352,18 @@ ZKP_HD inline void step_vtranscript(const VfyView& V, uint32_t job, Strobe& s) {
     st_sc(V.scal, VS_A, job, M, a); st_sc(V.scal, VS_B, job, M, b);
     for (uint32_t j = 0; j < lg; j++) { st_sc(V.scal, VS_U + j, job, M, u[j]); st_sc(V.scal, VS_UINV + j, job, M, uinv[j]); }
     // generator coefficients of B and B~
-    st_digits(V.digits, BASE_B, job, M, sc_add(sc_mul(wch, sc_sub(t_x, sc_mul(a, b))), sc_mul(c, sc_sub(t_x, delta))));
-    st_digits(V.digits, BASE_BB, job, M, sc_sub(sc_mul(c, t_xb), e_bl));
+    st_gen_coef(V, BASE_B, job, sc_add(sc_mul(wch, sc_sub(t_x, sc_mul(a, b))), sc_mul(c, sc_sub(t_x, delta))));
+    st_gen_coef(V, BASE_BB, job, sc_sub(sc_mul(c, t_xb), e_bl));
     // proof-point scalars
     const sc cz = sc_mul(c, zz);
-    st_sc(V.vscal, VP_V, job, M, sc_to_raw(sc_neg(cz)));
-    st_sc(V.vscal, VP_A, job, M, sc_raw_one());
-    st_sc(V.vscal, VP_S, job, M, sc_to_raw(x));
-    st_sc(V.vscal, VP_T1, job, M, sc_to_raw(sc_neg(sc_mul(c, x))));
-    st_sc(V.vscal, VP_T2, job, M, sc_to_raw(sc_neg(sc_mul(c, xx))));
+    st_point_scalar(V, VP_V, job, sc_neg(cz));
+    st_point_scalar(V, VP_A, job, sc_one());
+    st_point_scalar(V, VP_S, job, x);
+    st_point_scalar(V, VP_T1, job, sc_neg(sc_mul(c, x)));
+    st_point_scalar(V, VP_T2, job, sc_neg(sc_mul(c, xx)));
     for (uint32_t j = 0; j < lg; j++) {
-        st_sc(V.vscal, VP_L + j, job, M, sc_to_raw(sc_mul(u[j], u[j])));
-        st_sc(V.vscal, VP_R + j, job, M, sc_to_raw(sc_mul(uinv[j], uinv[j])));
+        st_point_scalar(V, VP_L + j, job, sc_mul(u[j], u[j]));
+        st_point_scalar(V, VP_R + j, job, sc_mul(uinv[j], uinv[j]));
     }
 }
 
@@ -346,9 +382,9 @@ ZKP_HD inline void step_vscalars(const VfyView& V, uint32_t i, uint32_t job) {
     const sc z = ld_sc(V.scal, VS_Z, job, M), zz = ld_sc(V.scal, VS_ZZ, job, M), a = ld_sc(V.scal, VS_A, job, M), b = ld_sc(V.scal, VS_B, job, M);
     sc yip = sc_one(), base = ld_sc(V.scal, VS_YINV, job, M);          // y^-i by square and multiply over the 6 bits of i
     for (uint32_t k = 0; k < 6; k++) { if ((i >> k) & 1u) yip = sc_mul(yip, base); base = sc_mul(base, base); }
-    st_digits(V.digits, BASE_G + i, job, M, sc_neg(sc_add(z, sc_mul(a, s_i))));
+    st_gen_coef(V, BASE_G + i, job, sc_neg(sc_add(z, sc_mul(a, s_i))));
     const sc h = sc_add(z, sc_mul(yip, sc_sub(sc_mul(zz, sc_from_u64(1ull << i)), sc_mul(b, s_r))));
-    st_digits(V.digits, BASE_H + i, job, M, h);
+    st_gen_coef(V, BASE_H + i, job, h);
 }
 
 // ---- step 4: scalar * proof point.  thread = (p, job)
@@ -357,7 +393,7 @@ ZKP_HD inline void step_vvarbase(const VfyView& V, uint32_t p, uint32_t job) {
     ge r = ge_identity();
     if (!V.bad[job] && vpoint_present(p, V.lgn[job])) {
         const ge pt = ld_ge(V.pts, p, job, M);
-        r = p == VP_A ? pt : ge_scalarmult_raw(pt, ld_sc(V.vscal, p, job, M));
+        r = (p == VP_A && V.rho == nullptr) ? pt : ge_scalarmult_raw(pt, ld_sc(V.vscal, p, job, M));
     }
     st_ge(V.partial, V.var_chunk0 + p, job, M, r);
 }

@@ -90,6 +90,32 @@ def test_full_batch_of_4096(hip):
     print("verified 4096 range envelopes in %.2f ms (host buffers)" % (dt * 1e3))
 
 
+def test_batch_check_and_per_job_check_agree(hip, oracle_c, monkeypatch):
+    """The random-linear-combination batch check (bpv_impl.inc, default from 4096 jobs up) forced on at 300 envelopes and forced
+    off: the same verdicts as the oracle either way -- a clean batch accepted in one piece, any bad envelope sends the batch
+    through the per-job check, which names exactly the bad ones."""
+    n = 300
+    v, mn, mx, seeds = workload(n, 11)
+    out, lens = gpu_prove(hip, v, mn, mx, seeds)
+    rng = np.random.default_rng(5)
+    bad = out.copy()
+    rows = rng.choice(n, 7, replace=False)
+    bad[rows, rng.integers(2, 1478, 7)] ^= 0x10
+    want = oracle_verify(oracle_c, bad, lens, mn, mx)[1]
+    assert want.sum() == n - 7
+    for env in ({"ZKP_HIP_BATCH_VERIFY_MIN": "64"}, {"ZKP_HIP_NO_BATCH_VERIFY": "1"}):
+        for k, val in env.items():
+            monkeypatch.setenv(k, val)
+        assert (gpu_verify(hip, out, lens, mn, mx) == 1).all()
+        assert (gpu_verify(hip, bad, lens, mn, mx) == want).all()
+        assert (gpu_verify(hip, out, lens, mn + 1, mx) == 0).all()
+        one = out.copy(); one[n - 1, 40] ^= 1                        # a single bad envelope at the end of the batch
+        got = gpu_verify(hip, one, lens, mn, mx)
+        assert got[:-1].all() and got[-1] == 0
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_threshold_verification_matches_oracle(hip, oracle_c):
     import ctypes
     import libzkp_amd as z
