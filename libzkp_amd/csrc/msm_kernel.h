@@ -132,6 +132,10 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
     if (active) T::store(m.partial, chunk, row, m.rows, T::from_gather(acc));
 }
 
+// (Tried in round 2: the same loop over a flat per-chunk step list, software-pipelined three deep so that an iteration only issues
+// loads -- entry of step i+1, digit word of step i+2, descriptor of step i+3 -- and never waits behind one.  Kernel times were
+// within 1 % of this loop (G1 4.01 vs 4.05 ms, G2 1.70 vs 1.67 ms at 1024 membership rows): the metadata loads at the head of an
+// iteration are not what separates this kernel from the bare addition loop of tools/g1_add_rate.hip)
 // Partial sums of one target: a block owns 64 consecutive rows, its 8 waves each add every 8th chunk partial for those
 // rows (lane = row: every load is a full 256-byte coalesced segment), then a 3-level tree through LDS joins the waves.
 static constexpr int SUM_TB = 512;

@@ -1,0 +1,43 @@
+// The ALU ceiling of the Groth16 G1 MSM loop: lanes add a point of a small in-register set to an XYZZ accumulator over and
+// over (g1_mmadd_lazy, the loop body of k_msm_gather<G1Msm>, with no table gathers, no digits, no metadata), at 1..4 waves per
+// SIMD.  The MSM kernel's additions/s against this figure is what its memory side and loop control cost; this figure
+// against 1 810 multiply-adds at the v_mad_u64_u32 issue rate is what the field arithmetic's non-multiply instructions cost.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ilibzkp_amd/csrc tools/g1_add_rate.hip -o build/tools/g1_add_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include "bn254_g.h"
+using namespace zkp;
+
+template <int MAXW>
+__global__ void __launch_bounds__(256, MAXW) k(const uint32_t* pts, uint32_t* out, int iters) {
+    g1_aff q[2];
+    for (int j = 0; j < 2; j++) for (int k = 0; k < 10; k++) { q[j].x.v[k] = pts[j * 20 + k]; q[j].y.v[k] = pts[j * 20 + 10 + k]; }
+    g1_xyzz acc; acc.X = q[0].x; acc.Y = q[0].y; acc.ZZ = fq_one(); acc.ZZZ = fq_one();
+    acc.X.v[0] ^= threadIdx.x & 1u;                       // not on the curve, which the formulas do not care about
+    for (int it = 0; it < iters; it++) {
+        g1_aff e = q[it & 1];
+        e.y = fq_select((it >> 1) & 1, fq_sub_k4(fq_zero(), e.y), e.y);
+        acc = g1_mmadd_lazy(acc, e);
+    }
+    uint32_t s = 0; for (int k = 0; k < 10; k++) s ^= acc.X.v[k] ^ acc.Y.v[k] ^ acc.ZZ.v[k] ^ acc.ZZZ.v[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int MAXW> void run(int waves, const uint32_t* d_pts) {
+    const int blocks = 256 * waves, iters = 400;
+    uint32_t* d; (void)hipMalloc(&d, (size_t)blocks * 256 * 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int r = 0; r < 4; r++) { (void)hipEventRecord(e0); k<MAXW><<<blocks, 256>>>(d_pts, d, iters); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms; }
+    const double adds = (double)blocks * 256 * iters;
+    printf("{\"launch_bounds_waves\": %d, \"waves_per_simd\": %d, \"ms\": %.3f, \"g_adds_per_s\": %.2f, \"t_mad_per_s\": %.2f}\n", MAXW, waves, best, adds / (best * 1e-3) / 1e9, adds * 1810 / (best * 1e-3) / 1e12);
+    (void)hipFree(d);
+}
+int main() {
+    uint32_t h[40]; for (int k = 0; k < 40; k++) h[k] = 0x1234567u * (k + 1) & 0x3ffffffu;
+    uint32_t* d_pts; (void)hipMalloc(&d_pts, sizeof h); (void)hipMemcpy(d_pts, h, sizeof h, hipMemcpyHostToDevice);
+    for (int w : {1, 2, 3}) run<3>(w, d_pts);            // 168-VGPR budget, as the MSM kernel
+    for (int w : {2, 4}) run<4>(w, d_pts);               // 128-VGPR budget
+    for (int w : {1, 2}) run<2>(w, d_pts);               // 256-VGPR budget
+    return 0;
+}
