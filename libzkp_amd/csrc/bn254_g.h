@@ -5,6 +5,7 @@
 // /root/reference/src/backend/snark.rs:364,442); serialisation follows ark-serialize's uncompressed form.
 #pragma once
 #include "bn254_fq.h"
+#include "bn254_fq9.h"
 
 namespace zkp {
 
@@ -126,6 +127,29 @@ ZKP_HD inline g1_xyzz g1_mmadd_lazy(const g1_xyzz& p, const Aff<fq>& q) {
     r.ZZZ = fq_mul(p.ZZZ, PPP);
     return r;
 }
+// The same addition on nine 29-bit limbs (bn254_fq9.h), the form k_msm_gather<G1Msm> runs in.  Value bounds in units of p, every
+// operand carried9: accumulator X < 8, Y < 4, ZZ, ZZZ < 2; table entry x, y < 4.  U2, S2 < 4*2/169+1 = 1.05; P < 9.05, R < 5.05;
+// PP < 1.49, PPP < 1.08, Q < 1.08, RR < 1.16; X3 < 5.16; Y3 < (5.05*9.08 + 4*1.08)/169 + 1 = 1.30; ZZ3, ZZZ3 < 1.02.
+struct g1_xyzz9 { fq9 X, Y, ZZ, ZZZ; };
+struct g1_aff9 { fq9 x, y; };
+ZKP_HD inline g1_xyzz9 g1_mmadd9(const g1_xyzz9& p, const g1_aff9& q) {
+    const fq9 U2 = fq9_mul(q.x, p.ZZ), S2 = fq9_mul(q.y, p.ZZZ);
+    const fq9 P = fq9_sub_k<8>(U2, p.X), Rv = fq9_sub_k<4>(S2, p.Y);
+    const fq9 PP = fq9_sq(P);
+    const fq9 PPP = fq9_mul(P, PP), Q = fq9_mul(p.X, PP);
+    const fq9 RR = fq9_sq(Rv);
+    g1_xyzz9 r;
+    r.X = fq9_sub2_k4(RR, PPP, Q);                                       // R^2 - PPP - 2 Q + 4p
+    r.Y = fq9_mul_add2(Rv, fq9_sub_k<8>(Q, r.X), fq9_neg_k<4>(p.Y), PPP);      // R (Q - X3) + (4p - Y1) PPP, one reduction
+    r.ZZ = fq9_mul(p.ZZ, PP);
+    r.ZZZ = fq9_mul(p.ZZZ, PPP);
+    return r;
+}
+ZKP_HD inline g1_xyzz9 xyzz9_from_jac(const Jac<fq>& p) {
+    const fq zz = fq_sq(p.Z);
+    return g1_xyzz9{fq9_from_fq(p.X), fq9_from_fq(p.Y), fq9_from_fq(zz), fq9_from_fq(fq_mul(zz, p.Z))};
+}
+ZKP_HD inline Jac<fq> jac_from_xyzz9(const g1_xyzz9& p) { return Jac<fq>{fq9_to_fq(fq9_mul(p.X, p.ZZ)), fq9_to_fq(fq9_mul(p.Y, p.ZZZ)), fq9_to_fq(p.ZZ)}; }
 // (X, Y, Z) Jacobian <-> XYZZ: ZZ = Z^2, ZZZ = Z^3 one way; the other way Z' = ZZ gives X' = X ZZ, Y' = Y ZZZ
 ZKP_HD inline g1_xyzz xyzz_from_jac(const Jac<fq>& p) { const fq zz = fq_sq(p.Z); return g1_xyzz{p.X, p.Y, zz, fq_mul(zz, p.Z)}; }
 ZKP_HD inline Jac<fq> jac_from_xyzz(const g1_xyzz& p) { return Jac<fq>{fq_reduce_weak(fq_mul(p.X, p.ZZ)), fq_reduce_weak(fq_mul(p.Y, p.ZZZ)), fq_reduce_weak(p.ZZ)}; }

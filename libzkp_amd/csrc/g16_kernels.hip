@@ -13,13 +13,15 @@ struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b
 #define ZKP_G1_GATHER_PREFETCH 1
 #endif
     static constexpr uint32_t GATHER_WAVES = ZKP_G1_GATHER_WAVES; static constexpr bool GATHER_PREFETCH = ZKP_G1_GATHER_PREFETCH != 0;      // k_msm_gather: 3 waves/SIMD, entries one step ahead
-    using GAcc = g1_xyzz;                                         // the gather loop accumulates in XYZZ coordinates (bn254_g.h)
-    static __device__ __forceinline__ GAcc to_gather(const g1_jac& a) { return xyzz_from_jac(a); }
-    static __device__ __forceinline__ g1_jac from_gather(const GAcc& a) { return jac_from_xyzz(a); }
+    // the gather loop accumulates in XYZZ coordinates on nine 29-bit limbs (bn254_g.h: g1_mmadd9); the key tables hold their
+    // entries in that form (x: words 0..8, y: words 9..17 of the 20-word entry; k_g16_build_table)
+    using GAcc = g1_xyzz9;
+    static __device__ __forceinline__ GAcc to_gather(const g1_jac& a) { return xyzz9_from_jac(a); }
+    static __device__ __forceinline__ g1_jac from_gather(const GAcc& a) { return jac_from_xyzz9(a); }
     static __device__ __forceinline__ GAcc accumulate_entry(const GAcc& acc, int32_t d, const uint32_t* e) {
-        g1_aff q; ZKP_UNROLL for (int k = 0; k < 10; k++) { q.x.v[k] = e[k]; q.y.v[k] = e[10 + k]; }
-        q.y = fq_select(d < 0, fq_sub_k4(fq_zero(), q.y), q.y);          // 4p - y: limbs < 2^27, fine as a product operand
-        return g1_mmadd_lazy(acc, q);
+        g1_aff9 q; ZKP_UNROLL for (int k = 0; k < 9; k++) { q.x.v[k] = e[k]; q.y.v[k] = e[9 + k]; }
+        q.y = fq9_select(d < 0, fq9_neg_k<4>(q.y), q.y);                 // entries are < 3p
+        return g1_mmadd9(acc, q);
     }
     static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {      // LDS A/B build
         const uint32_t* e = subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W;
@@ -93,7 +95,7 @@ __global__ void __launch_bounds__(TW) k_mimc_commit(const uint64_t* values, uint
 // multiples are produced in Jacobian form eight at a time and converted with ONE field inversion per eight (Montgomery's
 // trick), which is what keeps a 4096-entry sub-table affordable at key load.
 template <class F, uint32_t AFF_W>
-__global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, uint32_t nslots, uint32_t* table) {
+__global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, uint32_t nslots, uint32_t* table, uint32_t fmt9) {
     const uint32_t t = blockIdx.x * TW + threadIdx.x;
     if (t >= nslots * G16_NWIN) return;
     const uint32_t slot = t / G16_NWIN, win = t % G16_NWIN;
@@ -123,6 +125,14 @@ __global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, u
             Aff<F> a; a.x = f_mul(pts[k].X, zi2); a.y = f_mul(pts[k].Y, f_mul(zi2, zi));
             const uint32_t* ax = reinterpret_cast<const uint32_t*>(&a.x); const uint32_t* ay = reinterpret_cast<const uint32_t*>(&a.y);
             uint32_t* o = dst + (size_t)(e0 + k) * AFF_W;
+            if constexpr (sizeof(F) == sizeof(fq)) {
+                if (fmt9) {                                        // the G1 MSM's form: nine 29-bit limbs per coordinate, < 3p
+                    const fq9 x9 = fq9_from_fq(a.x), y9 = fq9_from_fq(a.y);
+                    for (uint32_t j = 0; j < 9; j++) { o[j] = x9.v[j]; o[9 + j] = y9.v[j]; }
+                    o[18] = 0; o[19] = 0;
+                    continue;
+                }
+            }
             for (uint32_t j = 0; j < FW; j++) { o[j] = ax[j]; o[FW + j] = ay[j]; }
         }
     }
@@ -144,8 +154,8 @@ template __global__ void k_msm_gather<G1Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_msm_gather<G2Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_sum_t<G1Msm>(ReduceView, uint32_t*);
 template __global__ void k_sum_t<G2Msm>(ReduceView, uint32_t*);
-template __global__ void k_g16_build_table<fq, 20>(const uint32_t*, uint32_t, uint32_t*);
-template __global__ void k_g16_build_table<fq2, 40>(const uint32_t*, uint32_t, uint32_t*);
+template __global__ void k_g16_build_table<fq, 20>(const uint32_t*, uint32_t, uint32_t*, uint32_t);
+template __global__ void k_g16_build_table<fq2, 40>(const uint32_t*, uint32_t, uint32_t*, uint32_t);
 
 // ================================================================================================ launchers
 void g16_launch_witness(const G16View& V, hipStream_t st) { k_g16_witness<<<(V.rows + TW - 1) / TW, TW, 0, st>>>(V); }
@@ -164,10 +174,12 @@ void g16_launch_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* 
     k_g16_final<<<dim3((V.rows + TW - 1) / TW, 3), TW, 0, st>>>(V, sum_g1, sum_g2, tmp_g1);
 }
 void g16_launch_mimc(const uint64_t* values, uint32_t n, const uint32_t* mimc_c, uint8_t* out, hipStream_t st) { k_mimc_commit<<<(n + TW - 1) / TW, TW, 0, st>>>(values, n, mimc_c, out); }
-void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uint32_t* table, hipStream_t st) {
+// msm_form: the table feeds k_msm_gather<G1Msm> (entries on nine 29-bit limbs); false = plain Fq limbs (the verifier's
+// gamma_abc_g1 tables, g16_verify.h)
+void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uint32_t* table, hipStream_t st, bool msm_form) {
     const uint32_t threads = nslots * G16_NWIN;
-    if (!g2) k_g16_build_table<fq, 20><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table);
-    else k_g16_build_table<fq2, 40><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table);
+    if (!g2) k_g16_build_table<fq, 20><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table, msm_form && G16_WBITS > 10 ? 1u : 0u);
+    else k_g16_build_table<fq2, 40><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table, 0u);
 }
 // > 64 KB of dynamic LDS needs the opt-in attribute; once per HIP device (called when a shard creates its Groth16 state)
 hipError_t g16_prepare_device() {

@@ -54,6 +54,33 @@ void emul_g1_xyzz_chain(const uint32_t o[16], const uint32_t* pts, const int* si
     }
     g1_serialize(out, jac_from_xyzz(acc));
 }
+// the chain on nine 29-bit limbs (g1_mmadd9, the form the kernel actually runs): table entries converted as k_g16_build_table
+// converts them; returns the largest limb seen in any accumulator coordinate's low limbs (must stay below 2^29) through *max_limb
+void emul_g1_xyzz9_chain(const uint32_t o[16], const uint32_t* pts, const int* signs, int n, uint32_t out[16], uint32_t* max_limb) {
+    g1_xyzz9 acc = xyzz9_from_jac(jac_dbl(jac_from_aff(load_g1(o))));
+    uint32_t mx = 0;
+    for (int i = 0; i < n; i++) {
+        const g1_aff a = load_g1(pts + 16 * i);
+        g1_aff9 q{fq9_from_fq(a.x), fq9_from_fq(a.y)};
+        q.y = fq9_select(signs[i] < 0, fq9_neg_k<4>(q.y), q.y);
+        acc = g1_mmadd9(acc, q);
+        for (int k = 0; k < 9; k++) { const uint32_t w[4] = {acc.X.v[k], acc.Y.v[k], acc.ZZ.v[k], acc.ZZZ.v[k]}; for (uint32_t x : w) if (x > mx) mx = x; }
+    }
+    *max_limb = mx;
+    g1_serialize(out, jac_from_xyzz9(acc));
+}
+// fq <-> fq9 round trip and one product through the nine-limb form: out = a * b mod p (raw in, raw out)
+void emul_fq9_mul(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) {
+    const fq9 x = fq9_from_fq(fq_from_raw(a)), y = fq9_from_fq(fq_from_raw(b));
+    fq_to_raw(out, fq9_to_fq(fq9_mul(x, y)));
+}
+void emul_fq9_ops(const uint32_t a[8], const uint32_t b[8], uint32_t sq[8], uint32_t fused[8], uint32_t sub[8]) {
+    const fq9 x = fq9_from_fq(fq_from_raw(a)), y = fq9_from_fq(fq_from_raw(b));
+    fq_to_raw(sq, fq9_to_fq(fq9_sq(x)));                                        // a^2
+    fq_to_raw(fused, fq9_to_fq(fq9_mul_add2(x, x, fq9_neg_k<8>(x), y)));        // a^2 + (8p - a) b
+    const fq9 one = fq9_from_fq(fq_one());                                      // products with it bring a value below 1.05 p
+    fq_to_raw(sub, fq9_to_fq(fq9_sub2_k4(x, fq9_mul(y, one), fq9_mul(fq9_sub_k<4>(y, x), one))));      // a - b - 2 (b - a) = 3 (a - b); subtrahends < 3.2 p
+}
 void emul_g2_lazy_chain(const uint32_t o[32], const uint32_t* pts, const int* signs, int n, uint32_t out[32]) {
     g2_jac acc = jac_dbl(jac_from_aff(load_g2(o)));
     for (int i = 0; i < n; i++) {

@@ -40,6 +40,15 @@ def test_fields(libs):
             if a % m and i < 15:
                 fn(4, W(a), W(c), out)
                 assert I(out) == pow(a, -1, m)
+    # the nine-limb form of the G1 MSM loop (bn254_fq9.h) through its conversions: product, squaring, fused double product, subtractions
+    o2, o3 = (ctypes.c_uint32 * 8)(), (ctypes.c_uint32 * 8)()
+    vals = [0, 1, 2, b.P - 1, b.P - 2, (b.P - 1) // 2, 2**253, 2**255, 2**256 - 1] + [rnd.randrange(b.P) for _ in range(150)]
+    for i, a in enumerate(vals):
+        c = vals[(i * 7 + 3) % len(vals)]
+        lib.emul_fq9_mul(W(a), W(c), out)
+        assert I(out) == a * c % b.P
+        lib.emul_fq9_ops(W(a), W(c), out, o2, o3)
+        assert I(out) == a * a % b.P and I(o2) == (a * a - a * c) % b.P and I(o3) == 3 * (a - c) % b.P
     for x in [0, 2**512 - 1] + [rnd.randrange(2**512) for _ in range(20)]:
         lib.emul_fr_from_wide(W(x, 16), out)
         assert I(out) == x % b.R
@@ -108,6 +117,9 @@ def test_msm_inner_loop_lazy(libs):
     assert I(o16).to_bytes(64, "little") == b.ser_g1(b.G1C.mul_pt(b.G1, total))
     lib.emul_g1_xyzz_chain((ctypes.c_uint32 * 16)(*g1w(b.G1C.mul_pt(b.G1, ko))), pts1, arr, n, o16)          # the XYZZ accumulator of the gather kernel
     assert I(o16).to_bytes(64, "little") == b.ser_g1(b.G1C.mul_pt(b.G1, total))
+    mx = ctypes.c_uint32()                                                                                    # ... and on nine 29-bit limbs, the form it runs in
+    lib.emul_g1_xyzz9_chain((ctypes.c_uint32 * 16)(*g1w(b.G1C.mul_pt(b.G1, ko))), pts1, arr, n, o16, ctypes.byref(mx))
+    assert I(o16).to_bytes(64, "little") == b.ser_g1(b.G1C.mul_pt(b.G1, total)) and mx.value < 1 << 29
     pts2 = (ctypes.c_uint32 * (32 * n))(*sum((g2w(b.G2C.mul_pt(b.G2, k)) for k in ks), []))
     lib.emul_g2_lazy_chain((ctypes.c_uint32 * 32)(*g2w(b.G2C.mul_pt(b.G2, ko))), pts2, arr, n, o32)
     assert I(o32).to_bytes(128, "little") == b.ser_g2(b.G2C.mul_pt(b.G2, total))
