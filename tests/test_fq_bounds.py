@@ -221,3 +221,57 @@ def test_safe_ops_used_by_generic_point_formulas():
     t2 = mul(add_l(a, a), add_l(a, a))
     reduce_weak(sub_k(4, t0, t1)); reduce_weak(sub_k(8, t2, add_l(t0, t1)))
     reduce_weak(mul(add_l(a, a), sub_k(4, a, a))); reduce_weak(dbl_l(mul(a, a)))
+
+
+# ---- the nine-limb form of the G1 MSM loop (bn254_fq9.h): operands are carried (limbs < 2^29), values tracked in units of p
+def header_constants9():
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "libzkp_amd", "csrc", "bn254_fq9.h")).read()
+    out = {}
+    for name in ("fq9_pl", "fq9_k2", "fq9_k4", "fq9_k8", "fq9_r10"):
+        m = re.search(name + r"\(int i\) \{ constexpr uint32_t m\[9\] = \{([^}]*)\}", src)
+        out[name] = [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")]
+    out["n0"] = int(re.search(r"#define ZKP_FQ9_N0 (0x[0-9a-f]+)u", src).group(1), 16)
+    return out
+
+
+def test_nine_limb_constants_and_column_sums():
+    c = header_constants9()
+    val = lambda l: sum(x << (29 * i) for i, x in enumerate(l))  # noqa: E731
+    assert val(c["fq9_pl"]) == P and val(c["fq9_k2"]) == 2 * P and val(c["fq9_k4"]) == 4 * P and val(c["fq9_k8"]) == 8 * P
+    assert all(x < 1 << 29 for name in ("fq9_pl", "fq9_k2", "fq9_k4", "fq9_k8", "fq9_r10") for x in c[name])
+    assert val(c["fq9_r10"]) == (1 << 260) % P and (c["n0"] * P + 1) % (1 << 29) == 0
+    m29 = (1 << 29) - 1
+    # widest column of a product: 9 operand products + 9 reduction products + the carry of the column before
+    col = 9 * m29 * m29 + 9 * m29 * max(c["fq9_pl"])
+    assert col + (col >> 29) < 1 << 64
+    # fq9_sq: doubled limbs (< 2^30) in the 4 mixed products of the widest column, one square, 8 reduction products
+    assert 4 * (2 * m29) * m29 + m29 * m29 + 9 * m29 * max(c["fq9_pl"]) + (col >> 29) < 1 << 64
+    # fq9_mul_add2: 18 operand products + 9 reduction products
+    col2 = 18 * m29 * m29 + 9 * m29 * max(c["fq9_pl"])
+    assert col2 + (col2 >> 29) < 1 << 64
+    # fq9_sub_k / fq9_sub2_k4: limb expressions fit int32 with the running carry
+    assert m29 + max(c["fq9_k8"]) + 1 < 1 << 31 and -(m29 + 2 * m29 + 4) > -(1 << 31)
+
+
+def test_g1_mmadd9_is_closed_over_its_value_bounds():
+    """g1_mmadd9 (bn254_g.h) in units of p: accumulator X < 8, Y < 4, ZZ, ZZZ < 2 and entries < 4 give the same bounds back, every
+    subtrahend is covered by the multiple of p added, and nothing comes near 2^261 = 169.28 p (so top limbs stay below 2^29)"""
+    from fractions import Fraction as F
+    rp = F(1 << 261, P)
+    mul = lambda a, b: a * b / rp + 1  # noqa: E731
+    X, Y, ZZ, ZZZ, qx, qy = F(8), F(4), F(3), F(3), F(4), F(4)                 # ZZ, ZZZ < 3 covers the converted accumulator a chunk starts from
+    U2, S2 = mul(qx, ZZ), mul(qy, ZZZ)
+    assert X <= 8 and Y <= 4                                  # fq9_sub_k<8>(U2, X), fq9_sub_k<4>(S2, Y)
+    Pv, Rv = U2 + 8, S2 + 4
+    PP = mul(Pv, Pv); PPP, Q, RR = mul(Pv, PP), mul(X, PP), mul(Rv, Rv)
+    assert PPP + 2 * Q < 4                                    # fq9_sub2_k4
+    X3 = RR + 4
+    assert X3 < 8                                             # fq9_sub_k<8>(Q, X3), and the next iteration's X
+    Y3 = (Rv * (Q + 8) + 4 * PPP) / rp + 1
+    ZZ3, ZZZ3 = mul(ZZ, PP), mul(ZZZ, PPP)
+    assert Y3 < 4 and ZZ3 < 2 and ZZZ3 < 2
+    assert max(Pv, Rv, X3, Q + 8) < rp / 8
+    # conversions: fq9_from_fq of a reduce_weak value (< 3p) starts inside the bounds; entries negated as 4p - y with y < 3p
+    assert 3 < 4 and 3 <= X and 3 <= Y and 3 <= ZZ
