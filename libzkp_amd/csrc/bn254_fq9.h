@@ -23,7 +23,12 @@ ZKP_HD constexpr uint32_t fq9_k2(int i) { constexpr uint32_t m[9] = {0x10f9fa8eu
 ZKP_HD constexpr uint32_t fq9_k4(int i) { constexpr uint32_t m[9] = {0x1f3f51cu, 0x41182dbu, 0x11ca8d3cu, 0xb548b43u, 0x161765e0u, 0xb6d0302u, 0x29b8504u, 0x197098d0u, 0xc19139u}; return m[i]; }
 ZKP_HD constexpr uint32_t fq9_k8(int i) { constexpr uint32_t m[9] = {0x3e7ea38u, 0x82305b6u, 0x3951a78u, 0x16a91687u, 0xc2ecbc0u, 0x16da0605u, 0x5370a08u, 0x12e131a0u, 0x1832273u}; return m[i]; }
 ZKP_HD constexpr uint32_t fq9_r10(int i) { constexpr uint32_t m[9] = {0x16fce4b4u, 0xa904407u, 0xa626a11u, 0x12109375u, 0x1014a498u, 0x100ec0c7u, 0x93e16a4u, 0x9c376eeu, 0x1f1642u}; return m[i]; }   // 2^260 mod p
-template <int K> ZKP_HD constexpr uint32_t fq9_kp(int i) { static_assert(K == 1 || K == 2 || K == 4 || K == 8, "multiples of p held as constants"); return K == 1 ? fq9_pl(i) : K == 2 ? fq9_k2(i) : K == 4 ? fq9_k4(i) : fq9_k8(i); }
+ZKP_HD constexpr uint32_t fq9_k16(int i) { constexpr uint32_t m[9] = {0x7cfd470u, 0x10460b6cu, 0x72a34f0u, 0xd522d0eu, 0x185d9781u, 0xdb40c0au, 0xa6e1411u, 0x5c26340u, 0x30644e7u}; return m[i]; }
+ZKP_HD constexpr uint32_t fq9_k32(int i) { constexpr uint32_t m[9] = {0xf9fa8e0u, 0x8c16d8u, 0xe5469e1u, 0x1aa45a1cu, 0x10bb2f02u, 0x1b681815u, 0x14dc2822u, 0xb84c680u, 0x60c89ceu}; return m[i]; }
+template <int K> ZKP_HD constexpr uint32_t fq9_kp(int i) {
+    static_assert(K == 1 || K == 2 || K == 4 || K == 8 || K == 16 || K == 32, "multiples of p held as constants");
+    return K == 1 ? fq9_pl(i) : K == 2 ? fq9_k2(i) : K == 4 ? fq9_k4(i) : K == 8 ? fq9_k8(i) : K == 16 ? fq9_k16(i) : fq9_k32(i);
+}
 
 ZKP_HD inline fq9 fq9_zero() { fq9 r; ZKP_UNROLL for (int i = 0; i < 9; i++) r.v[i] = 0; return r; }
 
@@ -87,6 +92,46 @@ ZKP_HD inline fq9 fq9_mul_add2(const fq9& a, const fq9& b, const fq9& c, const f
     r.v[8] = (uint32_t)acc;
     return r;
 }
+// (a b + c d + e f + g h) / 2^261 with one reduction: 36 + 9 products of < 2^58 per column, < 2^63.5 (the Fq2 combination
+// R W - Y1 J of the G2 addition is two of these instead of two Fq2 products)
+ZKP_HD inline fq9 fq9_mul_add4(const fq9& a, const fq9& b, const fq9& c, const fq9& d, const fq9& e, const fq9& f, const fq9& g, const fq9& h) {
+    uint32_t m[9]; fq9 r; uint64_t acc = 0;
+    ZKP_UNROLL for (int i = 0; i < 9; i++) {
+        ZKP_UNROLL for (int j = 0; j <= i; j++) {
+            acc += (uint64_t)a.v[j] * b.v[i - j]; acc += (uint64_t)c.v[j] * d.v[i - j];
+            acc += (uint64_t)e.v[j] * f.v[i - j]; acc += (uint64_t)g.v[j] * h.v[i - j];
+        }
+        ZKP_UNROLL for (int j = 0; j < i; j++) acc += (uint64_t)m[j] * fq9_pl(i - j);
+        m[i] = ((uint32_t)acc * ZKP_FQ9_N0) & ZKP_FQ9_MASK;
+        acc += (uint64_t)m[i] * fq9_pl(0);
+        acc >>= 29;
+    }
+    ZKP_UNROLL for (int i = 9; i < 17; i++) {
+        ZKP_UNROLL for (int j = i - 8; j < 9; j++) {
+            acc += (uint64_t)a.v[j] * b.v[i - j]; acc += (uint64_t)c.v[j] * d.v[i - j];
+            acc += (uint64_t)e.v[j] * f.v[i - j]; acc += (uint64_t)g.v[j] * h.v[i - j];
+        }
+        ZKP_UNROLL for (int j = i - 8; j < 9; j++) acc += (uint64_t)m[j] * fq9_pl(i - j);
+        r.v[i - 9] = (uint32_t)acc & ZKP_FQ9_MASK;
+        acc >>= 29;
+    }
+    r.v[8] = (uint32_t)acc;
+    return r;
+}
+// 2 a, limb-wise (limbs < 2^30): allowed as ONE operand of a plain fq9_mul (9 x 2^59 + 9 x 2^58 per column)
+ZKP_HD inline fq9 fq9_dbl_l(const fq9& a) { fq9 r; ZKP_UNROLL for (int i = 0; i < 9; i++) r.v[i] = a.v[i] << 1; return r; }
+// (neg ? -a : a) - b + K p in one carry pass (a + b < K p)
+template <int K> ZKP_HD inline fq9 fq9_sgn_sub_k(bool neg, const fq9& a, const fq9& b) {
+    fq9 r; int32_t c = 0;
+    ZKP_UNROLL for (int i = 0; i < 8; i++) {
+        const int32_t s = neg ? -(int32_t)a.v[i] : (int32_t)a.v[i];
+        const int32_t t = s - (int32_t)b.v[i] + (int32_t)fq9_kp<K>(i) + c;
+        r.v[i] = (uint32_t)t & ZKP_FQ9_MASK; c = t >> 29;
+    }
+    const int32_t s8 = neg ? -(int32_t)a.v[8] : (int32_t)a.v[8];
+    r.v[8] = (uint32_t)(s8 - (int32_t)b.v[8] + (int32_t)fq9_kp<K>(8) + c);
+    return r;
+}
 // a - b + K p (b < K p), carries propagated: limb differences stay within (-2^29, 2^30), the running carry within {-1, 0, 1}
 template <int K> ZKP_HD inline fq9 fq9_sub_k(const fq9& a, const fq9& b) {
     fq9 r; int32_t c = 0;
@@ -97,16 +142,17 @@ template <int K> ZKP_HD inline fq9 fq9_sub_k(const fq9& a, const fq9& b) {
     r.v[8] = (uint32_t)((int32_t)a.v[8] - (int32_t)b.v[8] + (int32_t)fq9_kp<K>(8) + c);
     return r;
 }
-// a - b - 2 c + 4 p in one carry pass (b + 2 c < 4 p): limb sums within (-2^31, 2^30), the running carry within [-4, 1]
-ZKP_HD inline fq9 fq9_sub2_k4(const fq9& a, const fq9& b, const fq9& c2) {
+// a - b - 2 c + K p in one carry pass (b + 2 c < K p): limb sums within (-2^31, 2^30), the running carry within [-4, 1]
+template <int K> ZKP_HD inline fq9 fq9_sub2_k(const fq9& a, const fq9& b, const fq9& c2) {
     fq9 r; int32_t c = 0;
     ZKP_UNROLL for (int i = 0; i < 8; i++) {
-        const int32_t t = (int32_t)a.v[i] - (int32_t)b.v[i] - (int32_t)(c2.v[i] << 1) + (int32_t)fq9_k4(i) + c;
+        const int32_t t = (int32_t)a.v[i] - (int32_t)b.v[i] - (int32_t)(c2.v[i] << 1) + (int32_t)fq9_kp<K>(i) + c;
         r.v[i] = (uint32_t)t & ZKP_FQ9_MASK; c = t >> 29;
     }
-    r.v[8] = (uint32_t)((int32_t)a.v[8] - (int32_t)b.v[8] - (int32_t)(c2.v[8] << 1) + (int32_t)fq9_k4(8) + c);
+    r.v[8] = (uint32_t)((int32_t)a.v[8] - (int32_t)b.v[8] - (int32_t)(c2.v[8] << 1) + (int32_t)fq9_kp<K>(8) + c);
     return r;
 }
+ZKP_HD inline fq9 fq9_sub2_k4(const fq9& a, const fq9& b, const fq9& c2) { return fq9_sub2_k<4>(a, b, c2); }
 // K p - a (a < K p)
 template <int K> ZKP_HD inline fq9 fq9_neg_k(const fq9& a) { return fq9_sub_k<K>(fq9_zero(), a); }
 // a + b, carried (values must leave the sum below 2^261)

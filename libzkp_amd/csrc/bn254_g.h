@@ -193,6 +193,50 @@ ZKP_HD inline Jac<fq2> g2_madd_lazy(const Jac<fq2>& p, const Aff<fq2>& q, bool n
     return r;
 }
 
+// The G2 MSM loop on nine 29-bit limbs: XYZZ coordinates over Fq2 = Fq[u]/(u^2 + 1) (mmadd-2008-s).  An Fq2 product is two
+// fused double products (a0 b0 + (Kp - a1) b1, a0 b1 + a1 b0: 486 multiply-adds, two reductions, one negation pass that several
+// products share); Y3 = R (Q - X3) - Y1 PPP is two fused quadruple products.  4 536 multiply-adds per addition where the
+// Karatsuba form on ten limbs (g2_madd_lazy, the host reference) takes 5 800.  Value bounds (units of p, every operand carried9;
+// tests/test_fq_bounds.py): X < 10.4, Y < 4, ZZ, ZZZ < 3 (< 2 after the first addition), entries < 3.
+struct fq2_9 { fq9 c0, c1; };
+struct g2_xyzz9 { fq2_9 X, Y, ZZ, ZZZ; };
+struct g2_aff9 { fq2_9 x, y; };
+// a * b with nb1 = K p - b.c1 supplied by the caller
+ZKP_HD inline fq2_9 fq2_9_mul(const fq2_9& a, const fq2_9& b, const fq9& nb1) {
+    return fq2_9{fq9_mul_add2(a.c0, b.c0, a.c1, nb1), fq9_mul_add2(a.c0, b.c1, a.c1, b.c0)};
+}
+// a^2 with na1 = K p - a.c1
+ZKP_HD inline fq2_9 fq2_9_sq(const fq2_9& a, const fq9& na1) { return fq2_9{fq9_mul_add2(a.c0, a.c0, a.c1, na1), fq9_mul(fq9_dbl_l(a.c0), a.c1)}; }
+ZKP_HD inline g2_xyzz9 g2_mmadd9(const g2_xyzz9& p, const g2_aff9& q, bool negate) {
+    const fq9 nZZ1 = fq9_neg_k<4>(p.ZZ.c1), nZZZ1 = fq9_neg_k<4>(p.ZZZ.c1);
+    const fq2_9 U2 = fq2_9_mul(q.x, p.ZZ, nZZ1), S2 = fq2_9_mul(q.y, p.ZZZ, nZZZ1);                   // < 1.11
+    const fq2_9 P{fq9_sub_k<16>(U2.c0, p.X.c0), fq9_sub_k<16>(U2.c1, p.X.c1)};                        // < 17.2
+    const fq2_9 Rv{fq9_sgn_sub_k<8>(negate, S2.c0, p.Y.c0), fq9_sgn_sub_k<8>(negate, S2.c1, p.Y.c1)}; // +-S2 - Y1 + 8p < 9.2
+    const fq2_9 PP = fq2_9_sq(P, fq9_neg_k<32>(P.c1));                                                // < 6
+    const fq9 nPP1 = fq9_neg_k<8>(PP.c1);
+    const fq2_9 PPP = fq2_9_mul(P, PP, nPP1), Q = fq2_9_mul(p.X, PP, nPP1);                           // < 2.8, < 2.0
+    const fq9 nR1 = fq9_neg_k<16>(Rv.c1);
+    const fq2_9 RR = fq2_9_sq(Rv, nR1);                                                               // < 2.4
+    g2_xyzz9 r;
+    r.X = fq2_9{fq9_sub2_k<8>(RR.c0, PPP.c0, Q.c0), fq9_sub2_k<8>(RR.c1, PPP.c1, Q.c1)};              // R^2 - PPP - 2Q + 8p < 10.4
+    const fq2_9 W{fq9_sub_k<16>(Q.c0, r.X.c0), fq9_sub_k<16>(Q.c1, r.X.c1)};                          // < 18
+    const fq9 nY0 = fq9_neg_k<4>(p.Y.c0), nY1 = fq9_neg_k<4>(p.Y.c1);
+    r.Y = fq2_9{fq9_mul_add4(Rv.c0, W.c0, nR1, W.c1, nY0, PPP.c0, p.Y.c1, PPP.c1),                    // Re(R W) - Re(Y1 PPP)
+                fq9_mul_add4(Rv.c0, W.c1, Rv.c1, W.c0, nY0, PPP.c1, nY1, PPP.c0)};                    // Im(R W) - Im(Y1 PPP)
+    r.ZZ = fq2_9_mul(PP, p.ZZ, nZZ1);
+    r.ZZZ = fq2_9_mul(PPP, p.ZZZ, nZZZ1);
+    return r;
+}
+ZKP_HD inline fq2_9 fq2_9_from_fq2(const fq2& a) { return fq2_9{fq9_from_fq(a.c0), fq9_from_fq(a.c1)}; }
+ZKP_HD inline fq2 fq2_9_to_fq2(const fq2_9& a) { return fq2{fq9_to_fq(a.c0), fq9_to_fq(a.c1)}; }
+ZKP_HD inline g2_xyzz9 g2_xyzz9_from_jac(const Jac<fq2>& p) {
+    const fq2 zz = f_sq(p.Z);
+    return g2_xyzz9{fq2_9_from_fq2(p.X), fq2_9_from_fq2(p.Y), fq2_9_from_fq2(zz), fq2_9_from_fq2(f_mul(zz, p.Z))};
+}
+ZKP_HD inline Jac<fq2> jac_from_g2_xyzz9(const g2_xyzz9& p) {      // Z' = ZZ: X' = X ZZ, Y' = Y ZZZ
+    return Jac<fq2>{fq2_9_to_fq2(fq2_9_mul(p.X, p.ZZ, fq9_neg_k<4>(p.ZZ.c1))), fq2_9_to_fq2(fq2_9_mul(p.Y, p.ZZZ, fq9_neg_k<4>(p.ZZZ.c1))), fq2_9_to_fq2(p.ZZ)};
+}
+
 // add-2007-bl (Jacobian + Jacobian): 11M + 5S
 template <class F> ZKP_HD inline Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
     if (jac_is_inf(p)) return q;

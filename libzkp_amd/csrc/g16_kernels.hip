@@ -40,10 +40,16 @@ struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
     using Acc = g2_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq2>(); }
     static constexpr uint32_t GATHER_WAVES = 2; static constexpr bool GATHER_PREFETCH = false;     // k_msm_gather: 256 VGPRs are taken by the addition itself
-    using GAcc = g2_jac;
-    static __device__ __forceinline__ GAcc to_gather(const g2_jac& a) { return a; }
-    static __device__ __forceinline__ g2_jac from_gather(const GAcc& a) { return a; }
-    static __device__ __forceinline__ Acc accumulate_entry(const Acc& acc, int32_t d, const uint32_t* e) {
+    // the gather loop: XYZZ coordinates over Fq2 on nine 29-bit limbs (bn254_g.h: g2_mmadd9); table entries in that form
+    // (x.c0, x.c1, y.c0, y.c1 at words 0, 9, 18, 27 of the 40-word entry)
+    using GAcc = g2_xyzz9;
+    static __device__ __forceinline__ GAcc to_gather(const g2_jac& a) { return g2_xyzz9_from_jac(a); }
+    static __device__ __forceinline__ g2_jac from_gather(const GAcc& a) { return jac_from_g2_xyzz9(a); }
+    static __device__ __forceinline__ GAcc accumulate_entry(const GAcc& acc, int32_t d, const uint32_t* e) {
+        g2_aff9 q; ZKP_UNROLL for (int k = 0; k < 9; k++) { q.x.c0.v[k] = e[k]; q.x.c1.v[k] = e[9 + k]; q.y.c0.v[k] = e[18 + k]; q.y.c1.v[k] = e[27 + k]; }
+        return g2_mmadd9(acc, q, d < 0);
+    }
+    static __device__ __forceinline__ Acc accumulate_entry(const Acc& acc, int32_t d, const uint32_t* e) {      // ten-limb entries (LDS A/B build)
         g2_aff q; ZKP_UNROLL for (int k = 0; k < 10; k++) { q.x.c0.v[k] = e[k]; q.x.c1.v[k] = e[10 + k]; q.y.c0.v[k] = e[20 + k]; q.y.c1.v[k] = e[30 + k]; }
         return g2_madd_lazy(acc, q, d < 0);
     }
@@ -125,13 +131,12 @@ __global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, u
             Aff<F> a; a.x = f_mul(pts[k].X, zi2); a.y = f_mul(pts[k].Y, f_mul(zi2, zi));
             const uint32_t* ax = reinterpret_cast<const uint32_t*>(&a.x); const uint32_t* ay = reinterpret_cast<const uint32_t*>(&a.y);
             uint32_t* o = dst + (size_t)(e0 + k) * AFF_W;
-            if constexpr (sizeof(F) == sizeof(fq)) {
-                if (fmt9) {                                        // the G1 MSM's form: nine 29-bit limbs per coordinate, < 3p
-                    const fq9 x9 = fq9_from_fq(a.x), y9 = fq9_from_fq(a.y);
-                    for (uint32_t j = 0; j < 9; j++) { o[j] = x9.v[j]; o[9 + j] = y9.v[j]; }
-                    o[18] = 0; o[19] = 0;
-                    continue;
-                }
+            if (fmt9) {                                            // the MSM loops' form: nine 29-bit limbs per Fq coordinate, < 3p
+                const fq* c = reinterpret_cast<const fq*>(&a);     // x then y (G1) / x.c0, x.c1, y.c0, y.c1 (G2)
+                constexpr uint32_t NC = AFF_W / 10;
+                for (uint32_t t = 0; t < NC; t++) { const fq9 v = fq9_from_fq(c[t]); for (uint32_t j = 0; j < 9; j++) o[9 * t + j] = v.v[j]; }
+                for (uint32_t j = 9 * NC; j < AFF_W; j++) o[j] = 0;
+                continue;
             }
             for (uint32_t j = 0; j < FW; j++) { o[j] = ax[j]; o[FW + j] = ay[j]; }
         }
@@ -174,12 +179,12 @@ void g16_launch_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* 
     k_g16_final<<<dim3((V.rows + TW - 1) / TW, 3), TW, 0, st>>>(V, sum_g1, sum_g2, tmp_g1);
 }
 void g16_launch_mimc(const uint64_t* values, uint32_t n, const uint32_t* mimc_c, uint8_t* out, hipStream_t st) { k_mimc_commit<<<(n + TW - 1) / TW, TW, 0, st>>>(values, n, mimc_c, out); }
-// msm_form: the table feeds k_msm_gather<G1Msm> (entries on nine 29-bit limbs); false = plain Fq limbs (the verifier's
-// gamma_abc_g1 tables, g16_verify.h)
+// msm_form: the table feeds k_msm_gather (entries on nine 29-bit limbs); false = plain Fq limbs (the verifier's gamma_abc_g1
+// tables, g16_verify.h)
 void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uint32_t* table, hipStream_t st, bool msm_form) {
     const uint32_t threads = nslots * G16_NWIN;
     if (!g2) k_g16_build_table<fq, 20><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table, msm_form && G16_WBITS > 10 ? 1u : 0u);
-    else k_g16_build_table<fq2, 40><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table, 0u);
+    else k_g16_build_table<fq2, 40><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table, msm_form && G16_WBITS > 10 ? 1u : 0u);
 }
 // > 64 KB of dynamic LDS needs the opt-in attribute; once per HIP device (called when a shard creates its Groth16 state)
 hipError_t g16_prepare_device() {

@@ -89,6 +89,20 @@ void emul_g2_lazy_chain(const uint32_t o[32], const uint32_t* pts, const int* si
     }
     g2_serialize(out, acc);
 }
+// the G2 chain on nine 29-bit limbs (g2_mmadd9), entries converted as the table builder converts them
+void emul_g2_xyzz9_chain(const uint32_t o[32], const uint32_t* pts, const int* signs, int n, uint32_t out[32], uint32_t* max_limb) {
+    g2_xyzz9 acc = g2_xyzz9_from_jac(jac_dbl(jac_from_aff(load_g2(o))));
+    uint32_t mx = 0;
+    for (int i = 0; i < n; i++) {
+        const g2_aff a = load_g2(pts + 32 * i);
+        const g2_aff9 q{fq2_9_from_fq2(a.x), fq2_9_from_fq2(a.y)};
+        acc = g2_mmadd9(acc, q, signs[i] < 0);
+        const fq9* c = reinterpret_cast<const fq9*>(&acc);
+        for (int t = 0; t < 8; t++) for (int k = 0; k < 9; k++) if (c[t].v[k] > mx) mx = c[t].v[k];
+    }
+    *max_limb = mx;
+    g2_serialize(out, jac_from_g2_xyzz9(acc));
+}
 void emul_fr_op(int op, const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) { fp_op<FrParams>(op, a, b, out); }
 void emul_fr_from_wide(const uint32_t w[16], uint32_t out[8]) { fp_to_raw(out, fp_from_wide<FrParams>(w)); }
 // serialize(k1*P + k2*Q) with P, Q affine (raw coords); uses madd for the first term path, add, dbl via jac_mul_raw

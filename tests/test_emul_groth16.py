@@ -123,6 +123,8 @@ def test_msm_inner_loop_lazy(libs):
     pts2 = (ctypes.c_uint32 * (32 * n))(*sum((g2w(b.G2C.mul_pt(b.G2, k)) for k in ks), []))
     lib.emul_g2_lazy_chain((ctypes.c_uint32 * 32)(*g2w(b.G2C.mul_pt(b.G2, ko))), pts2, arr, n, o32)
     assert I(o32).to_bytes(128, "little") == b.ser_g2(b.G2C.mul_pt(b.G2, total))
+    lib.emul_g2_xyzz9_chain((ctypes.c_uint32 * 32)(*g2w(b.G2C.mul_pt(b.G2, ko))), pts2, arr, n, o32, ctypes.byref(mx))      # the form k_msm_gather<G2Msm> runs in
+    assert I(o32).to_bytes(128, "little") == b.ser_g2(b.G2C.mul_pt(b.G2, total)) and mx.value < 1 << 29
 
 
 def _run(lib, kind, value, the_set, seed):

@@ -275,3 +275,38 @@ def test_g1_mmadd9_is_closed_over_its_value_bounds():
     assert max(Pv, Rv, X3, Q + 8) < rp / 8
     # conversions: fq9_from_fq of a reduce_weak value (< 3p) starts inside the bounds; entries negated as 4p - y with y < 3p
     assert 3 < 4 and 3 <= X and 3 <= Y and 3 <= ZZ
+
+
+def test_g2_mmadd9_is_closed_over_its_value_bounds():
+    """g2_mmadd9 (bn254_g.h), per Fq component in units of p: X < 10.4, Y < 4, ZZ, ZZZ < 3 and entries < 3 give X, Y within the same
+    bounds and ZZ, ZZZ < 2; every subtrahend / negated operand is covered by the multiple of p used; nothing comes near 2^261."""
+    from fractions import Fraction as F
+    rp = F(1 << 261, P)
+    m2 = lambda a, b, c, d: (a * b + c * d) / rp + 1  # noqa: E731
+    X, Y, ZZ, ZZZ, q = F(104, 10), F(4), F(3), F(3), F(3)
+    assert ZZ < 4 and ZZZ < 4                                   # nZZ1, nZZZ1 = 4p - .
+    U2 = max(m2(q, ZZ, q, 4), m2(q, ZZ, q, ZZ)); S2 = max(m2(q, ZZZ, q, 4), m2(q, ZZZ, q, ZZZ))
+    assert X < 16 and S2 + Y < 8                                # P = U2 - X + 16p ; R = +-S2 - Y + 8p
+    Pv, Rv = U2 + 16, S2 + 8
+    assert Pv < 32                                              # nP1 = 32p - P1
+    PP = max(m2(Pv, Pv, Pv, 32), 2 * Pv * Pv / rp + 1)
+    assert PP < 8                                               # nPP1 = 8p - PP1
+    PPP = max(m2(Pv, PP, Pv, 8), m2(Pv, PP, Pv, PP)); Q = max(m2(X, PP, X, 8), m2(X, PP, X, PP))
+    assert Rv < 16                                              # nR1 = 16p - R1
+    RR = max(m2(Rv, Rv, Rv, 16), 2 * Rv * Rv / rp + 1)
+    assert PPP + 2 * Q < 8                                      # X3 = RR - PPP - 2Q + 8p
+    X3 = RR + 8
+    assert X3 <= X and X3 < 16                                  # W = Q - X3 + 16p
+    W = Q + 16
+    assert Y <= 4                                               # nY0, nY1 = 4p - .
+    Y3 = max((Rv * W + 16 * W + 4 * PPP + Y * PPP) / rp + 1, (Rv * W + Rv * W + 4 * PPP + 4 * PPP) / rp + 1)
+    ZZ3 = max(m2(PP, ZZ, PP, 4), m2(PP, ZZ, PP, ZZ)); ZZZ3 = max(m2(PPP, ZZZ, PPP, 4), m2(PPP, ZZZ, PPP, ZZZ))
+    assert Y3 < 4 and ZZ3 < 2 and ZZZ3 < 2
+    assert max(Pv, W, 32) < rp / 4
+    # fq9_mul_add4 columns: 36 operand products + 9 reduction products of carried limbs
+    m29 = (1 << 29) - 1
+    col = 36 * m29 * m29 + 9 * m29 * m29
+    assert col + (col >> 29) < 1 << 64
+    # fq9_mul with one limb-wise doubled operand (fq2_9_sq): 9 products of < 2^59 + 9 reduction products
+    col = 9 * (2 * m29) * m29 + 9 * m29 * m29
+    assert col + (col >> 29) < 1 << 64
