@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 BATCH = 4096
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md
 MAD_ISSUE_T = 35.157                     # T v_mad_u64_u32 lane-ops/s, isolated issue-rate measurement (profiles/r02_fe_microbench.json)
-MADS_PER_G1_MADD = 7 * 200 + 4 * 155     # madd-2007-bl: 7 products of 200 mads, 4 squarings of 155 (bn254_fq.h)
+MADS_PER_G1_MADD = 7 * 162 + 2 * 126 + 243      # g1_mmadd9 (XYZZ, nine 29-bit limbs): 7 products, 2 squarings, 1 fused double product (bn254_fq9.h)
+G1_BARE_LOOP_GADDS = 16.99               # G additions/s of the bare addition loop at 3 waves/SIMD, no loads (tools/g1_add_rate.hip, profiles/r02_g1_add_rate.jsonl)
 MADS_PER_ED_MADD = 7 * 100               # mixed addition with an affine-Niels entry: 7 GF(2^255-19) products of 100 mads
 ALGO_BYTES = {"range": 24 + 32 + 1478, "equality": 16 + 32 + 298, "membership16": 8 + 128 + 32 + 430}
 
@@ -244,7 +245,9 @@ def main():
         g1_avg_ms = g1[0] / max(1, g1[1])
         # algorithmic bytes one G1 MSM launch must move: an equality launch serves its 346 B/proof ops, a membership
         # launch its 598 B/proof ops; the steps alternate one of each, so the per-launch average is the mean of the two
-        algo_launch = (ALGO_BYTES["equality"] * counts["equality"] + ALGO_BYTES["membership16"] * counts["membership"]) / 2.0
+        # (the G1 MSM of a circuit is two launches since the split pipeline -- A/B1 and the l/h sum -- each credited half)
+        g1_launches_per_step = max(1.0, g1[1] / max(1, args.steps))
+        algo_launch = (ALGO_BYTES["equality"] * counts["equality"] + ALGO_BYTES["membership16"] * counts["membership"]) / g1_launches_per_step
         achieved = algo_launch / (g1_avg_ms * 1e-3) / 1e9 if g1_avg_ms > 0 else 0.0
         g1_mad_rate = g1[2] * MADS_PER_G1_MADD / (g1[0] * 1e-3) / 1e12 if g1[0] > 0 else 0.0        # T mad/s
         traffic, traffic_src = None, None
@@ -256,7 +259,7 @@ def main():
             "metric": "proofs/sec (whole node) + ms/proof p50, 4096-proof mixed batch (range / equality / membership / improvement) per MI355X",
             "value": total / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32/u64 integer limbs (10x25.5-bit GF(2^255-19), 10x26-bit BN254 Fq, 8x32-bit Fr and scalars mod l, 2x64-bit f128)", "data": "synthetic",
+            "dtype": "u32/u64 integer limbs (10x25.5-bit GF(2^255-19), BN254 Fq on 9x29-bit limbs in the MSM loops and 10x26-bit elsewhere, 8x32-bit Fr and scalars mod l, 2x64-bit f128)", "data": "synthetic",
             "config": {"workload": "process_batch of %d mixed ops, i mod 4 = prove_range(v,0,2^32) / prove_equality / prove_membership(16-element set) / "
                                    "prove_improvement, seed 5 (BASELINE.md C5's mix at the metric's 4096-op size)" % n,
                        "ops_per_gpu_per_step": n, "ops_by_variant": counts, "proof_bytes_per_step": out_bytes,
@@ -273,8 +276,11 @@ def main():
                                  "other variants' kernels share the GPU"},
             "roofline_valu": {"bound": "valu-int", "achieved": g1_mad_rate, "peak": MAD_ISSUE_T, "unit": "T v_mad_u64_u32/s", "frac": g1_mad_rate / MAD_ISSUE_T,
                               "kernel": "k_msm_gather<G1Msm>", "point_additions_per_step": g1[2] / max(1, args.steps), "mads_per_point_addition": MADS_PER_G1_MADD,
+                              "g_additions_per_s": g1[2] / (g1[0] * 1e-3) / 1e9 if g1[0] > 0 else 0.0,
+                              "fraction_of_bare_loop": (g1[2] / (g1[0] * 1e-3) / 1e9 / G1_BARE_LOOP_GADDS) if g1[0] > 0 else 0.0,
                               "peak_source": "profiles/r02_fe_microbench.json: isolated v_mad_u64_u32 issue rate (the multiply-adds of the field products only; "
-                                             "carries, masks and loads share the same issue slots, a pure product chain reaches 73 % of it)"},
+                                             "carries, masks and loads share the same issue slots: a pure product chain reaches 75 % of it, the bare addition loop "
+                                             "(profiles/r02_g1_add_rate.jsonl) 75 %); launch durations are taken while the other variants' kernels share the GPU"},
             "other_msm_kernels": {
                 "k_msm_gather<G2Msm>": {"avg_launch_ms": g2[0] / max(1, g2[1]), "launches": g2[1], "ms_per_step": g2[0] / max(1, args.steps)},
                 "k_msm_dma<EdMsm>": {"avg_launch_ms": ed[0] / max(1, ed[1]), "launches": ed[1], "ms_per_step": ed[0] / max(1, args.steps),
