@@ -128,12 +128,14 @@ inline HostCircuitTables build_circuit_tables(const HostR1CS& cs) {
     for (uint32_t s = 0; s < lg; s++) { for (int i = 0; i < 7; i++) e[i] = (e[i] >> 1) | (e[i + 1] << 31); e[7] >>= 1; }
     const fr g = fp_from_u64<FrParams>(5), w = fr_pow_words(g, e);
     const fr winv = fp_inv(w), ginv = fp_inv(g), minv = fp_inv(fp_from_u64<FrParams>(m));
+    // the domain tables are read by the QAP step only, which works on nine 29-bit limbs (bn254_fr9.h): nine words per element
+    auto put_fr9 = [](std::vector<uint32_t>& v, const fr& x) { const fr9 y = fr9_from_fr(x); for (int i = 0; i < 9; i++) v.push_back(y.v[i]); };
     fr a = fp_one<FrParams>(), b = a;
-    for (uint32_t j = 0; j < m / 2; j++) { put_fr(T.tw, a); put_fr(T.tw_inv, b); a = fp_mul(a, w); b = fp_mul(b, winv); }
+    for (uint32_t j = 0; j < m / 2; j++) { put_fr9(T.tw, a); put_fr9(T.tw_inv, b); a = fp_mul(a, w); b = fp_mul(b, winv); }
     a = minv; b = minv;
-    for (uint32_t i = 0; i < m; i++) { put_fr(T.coset, a); put_fr(T.coset_inv, b); a = fp_mul(a, g); b = fp_mul(b, ginv); }
+    for (uint32_t i = 0; i < m; i++) { put_fr9(T.coset, a); put_fr9(T.coset_inv, b); a = fp_mul(a, g); b = fp_mul(b, ginv); }
     fr gm = fp_one<FrParams>(); for (uint32_t i = 0; i < m; i++) gm = fp_mul(gm, g);
-    put_fr(T.zinv, fp_inv(fp_sub(gm, fp_one<FrParams>())));
+    put_fr9(T.zinv, fp_inv(fp_sub(gm, fp_one<FrParams>())));
     return T;
 }
 

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(TB) k_g16_zdigits(G16View V) {
 }
 struct DevSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
 // one workgroup = one proof; the three polynomials (a, b, c evaluations -> h) live in LDS, word-major
-// 512 lanes: the 96 KB LDS image of a membership proof allows one workgroup per CU, so the workgroup itself has to bring the
+// 512 lanes: the 108 KB LDS image of a membership proof allows one workgroup per CU, so the workgroup itself has to bring the
 // waves (2 per SIMD) that hide the LDS latency of the butterfly stages
 static constexpr int QAP_TB = 512;
 __global__ void __launch_bounds__(QAP_TB) k_g16_qap(G16View V, G16Circuit C) {
@@ -166,7 +166,7 @@ template __global__ void k_g16_build_table<fq2, 40>(const uint32_t*, uint32_t, u
 void g16_launch_witness(const G16View& V, hipStream_t st) { k_g16_witness<<<(V.rows + TW - 1) / TW, TW, 0, st>>>(V); }
 void g16_launch_zdigits(const G16View& V, hipStream_t st) { k_g16_zdigits<<<dim3((V.rows + TB - 1) / TB, V.nv), TB, 0, st>>>(V); }
 hipError_t g16_launch_qap(const G16View& V, const G16Circuit& C, hipStream_t st) {
-    const size_t lds = (size_t)3 * 8 * C.m * 4;
+    const size_t lds = (size_t)3 * 9 * C.m * 4;         // three polynomials of nine-limb elements (54 KB at m = 512, 108 KB at m = 1024)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_g16_qap), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     k_g16_qap<<<V.rows, QAP_TB, lds, st>>>(V, C);

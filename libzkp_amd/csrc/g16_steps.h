@@ -8,6 +8,7 @@
 // LDS-streamed-window kernel over the proving key's points (same kernel template as the Bulletproofs path).
 #pragma once
 #include "bn254_g.h"
+#include "bn254_fr9.h"
 #include "keccak.h"
 #include "sc25519.h"
 
@@ -169,11 +170,13 @@ ZKP_HD inline uint32_t g16_bitrev(uint32_t x, uint32_t bits) {
 
 // The QAP witness map of ONE proof on a word-major image x[poly][word][element] (LDS on the GPU).  `nthreads` lanes
 // cooperate; `sync` is the workgroup barrier.  Reference semantic: LibsnarkReduction::witness_map_from_matrices.
+// the three polynomials of a proof as nine-limb elements (bn254_fr9.h), word-major: 3 x 9 x m words
 struct G16Lds {
     uint32_t* base; uint32_t m;
-    ZKP_HD fr ld(uint32_t poly, uint32_t e) const { fr r; ZKP_UNROLL for (int k = 0; k < 8; k++) r.v[k] = base[((size_t)poly * 8 + k) * m + e]; return r; }
-    ZKP_HD void st(uint32_t poly, uint32_t e, const fr& v) const { ZKP_UNROLL for (int k = 0; k < 8; k++) base[((size_t)poly * 8 + k) * m + e] = v.v[k]; }
+    ZKP_HD fr9 ld(uint32_t poly, uint32_t e) const { fr9 r; ZKP_UNROLL for (int k = 0; k < 9; k++) r.v[k] = base[((size_t)poly * 9 + k) * m + e]; return r; }
+    ZKP_HD void st(uint32_t poly, uint32_t e, const fr9& v) const { ZKP_UNROLL for (int k = 0; k < 9; k++) base[((size_t)poly * 9 + k) * m + e] = v.v[k]; }
 };
+ZKP_HD inline fr9 ld_fr9_c(const uint32_t* p, uint32_t idx) { fr9 r; ZKP_UNROLL for (int k = 0; k < 9; k++) r.v[k] = p[(size_t)idx * 9 + k]; return r; }
 // phase functions; each is called by every lane `tid` of the workgroup with a barrier between phases
 ZKP_HD inline void g16_qap_load(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t row, uint32_t tid, uint32_t nthreads) {
     const uint32_t nc = C.n_rows;
@@ -187,7 +190,7 @@ ZKP_HD inline void g16_qap_load(const G16View& V, const G16Circuit& C, const G16
             a = ld_fr(V.z, j - nc, row, V.rows);                    // a[n_constraints + i] = z_i (instance)
         }
         const uint32_t p = g16_bitrev(j, C.logm);                   // DIT inverse transform wants bit-reversed input
-        L.st(0, p, a); L.st(1, p, b); L.st(2, p, c);
+        L.st(0, p, fr9_from_fr(a)); L.st(1, p, fr9_from_fr(b)); L.st(2, p, fr9_from_fr(c));      // < 1.4 r each
     }
 }
 // one DIT stage (len = 2*half) on `npoly` polynomials with twiddle table tw (stride m/len)
@@ -195,10 +198,10 @@ ZKP_HD inline void g16_dit_stage(const G16Circuit& C, const G16Lds& L, const uin
     const uint32_t len = 2 * half, tstride = C.m / len;
     for (uint32_t k = tid; k < C.m / 2; k += nthreads) {
         const uint32_t grp = k / half, j = k % half, i0 = grp * len + j, i1 = i0 + half;
-        const fr w = ld_fr_c(tw, j * tstride);
-        for (uint32_t p = 0; p < npoly; p++) {
-            const fr u = L.ld(p, i0), v = fp_mul(L.ld(p, i1), w);
-            L.st(p, i0, fp_add(u, v)); L.st(p, i1, fp_sub(u, v));
+        const fr9 w = ld_fr9_c(tw, j * tstride);
+        for (uint32_t p = 0; p < npoly; p++) {                 // elements grow by <= 2 r per stage: < 22 r after ten (bn254_fr9.h)
+            const fr9 u = L.ld(p, i0), v = fr9_mul(L.ld(p, i1), w);
+            L.st(p, i0, fr9_add(u, v)); L.st(p, i1, fr9_sub_k<2>(u, v));
         }
     }
 }
@@ -206,27 +209,27 @@ ZKP_HD inline void g16_dif_stage(const G16Circuit& C, const G16Lds& L, const uin
     const uint32_t len = 2 * half, tstride = C.m / len;
     for (uint32_t k = tid; k < C.m / 2; k += nthreads) {
         const uint32_t grp = k / half, j = k % half, i0 = grp * len + j, i1 = i0 + half;
-        const fr w = ld_fr_c(tw, j * tstride);
-        for (uint32_t p = 0; p < npoly; p++) {
-            const fr u = L.ld(p, i0), v = L.ld(p, i1);
-            L.st(p, i0, fp_add(u, v)); L.st(p, i1, fp_mul(fp_sub(u, v), w));
+        const fr9 w = ld_fr9_c(tw, j * tstride);
+        for (uint32_t p = 0; p < npoly; p++) {                 // inputs < 2.3 r; the sum is brought back below 2.3 r, the product below 1.1 r
+            const fr9 u = L.ld(p, i0), v = L.ld(p, i1);
+            L.st(p, i0, fr9_reduce_weak(fr9_add(u, v))); L.st(p, i1, fr9_mul(fr9_sub_k<4>(u, v), w));
         }
     }
 }
 ZKP_HD inline void g16_scale(const G16Circuit& C, const G16Lds& L, const uint32_t* tab, uint32_t npoly, uint32_t tid, uint32_t nthreads) {
     for (uint32_t i = tid; i < C.m; i += nthreads) {
-        const fr f = ld_fr_c(tab, i);
-        for (uint32_t p = 0; p < npoly; p++) L.st(p, i, fp_mul(L.ld(p, i), f));
+        const fr9 f = ld_fr9_c(tab, i);
+        for (uint32_t p = 0; p < npoly; p++) L.st(p, i, fr9_mul(L.ld(p, i), f));
     }
 }
 ZKP_HD inline void g16_pointwise(const G16Circuit& C, const G16Lds& L, uint32_t tid, uint32_t nthreads) {
-    const fr zinv = ld_fr_c(C.zinv, 0);
+    const fr9 zinv = ld_fr9_c(C.zinv, 0);
     for (uint32_t i = tid; i < C.m; i += nthreads)
-        L.st(0, i, fp_mul(fp_sub(fp_mul(L.ld(0, i), L.ld(1, i)), L.ld(2, i)), zinv));
+        L.st(0, i, fr9_mul(fr9_sub_k<4>(fr9_mul(L.ld(0, i), L.ld(1, i)), L.ld(2, i)), zinv));
 }
 ZKP_HD inline void g16_store_h(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t row, uint32_t tid, uint32_t nthreads) {
     for (uint32_t i = tid; i + 1 < C.m; i += nthreads)
-        st_fr_digits(V.sdig, g16_sc_h(V) + i, row, V.rows, fp_mul(L.ld(0, i), ld_fr_c(C.coset_inv, i)));
+        st_fr_digits(V.sdig, g16_sc_h(V) + i, row, V.rows, fr9_to_fr<FrParams>(fr9_mul(L.ld(0, i), ld_fr9_c(C.coset_inv, i))));
 }
 // the whole witness map, written so that host emulation (nthreads = 1, sync = no-op) and the kernel share it
 template <class Sync>

@@ -310,3 +310,49 @@ def test_g2_mmadd9_is_closed_over_its_value_bounds():
     # fq9_mul with one limb-wise doubled operand (fq2_9_sq): 9 products of < 2^59 + 9 reduction products
     col = 9 * (2 * m29) * m29 + 9 * m29 * m29
     assert col + (col >> 29) < 1 << 64
+
+
+def test_fr9_constants_and_ntt_growth():
+    """bn254_fr9.h: constants, column sums, and the value bounds of the QAP step's transforms (units of r)"""
+    import os
+    import re
+    from fractions import Fraction as F
+    R_ = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+    src = open(os.path.join(os.path.dirname(__file__), "..", "libzkp_amd", "csrc", "bn254_fr9.h")).read()
+    c = {}
+    for name in ("fr9_pl", "fr9_k2", "fr9_k4", "fr9_k32", "fr9_one", "fr9_r256"):
+        m = re.search(name + r"\(int i\) \{ constexpr uint32_t m\[9\] = \{([^}]*)\}", src)
+        c[name] = [int(x.strip().rstrip("u"), 16) for x in m.group(1).split(",")]
+    val = lambda l: sum(x << (29 * i) for i, x in enumerate(l))  # noqa: E731
+    assert val(c["fr9_pl"]) == R_ and val(c["fr9_k2"]) == 2 * R_ and val(c["fr9_k4"]) == 4 * R_ and val(c["fr9_k32"]) == 32 * R_
+    assert val(c["fr9_one"]) == (1 << 261) % R_ and val(c["fr9_r256"]) == (1 << 256) % R_
+    assert all(x < 1 << 29 for v in c.values() for x in v)
+    n0 = int(re.search(r"#define ZKP_FR9_N0 (0x[0-9a-f]+)u", src).group(1), 16)
+    assert (n0 * R_ + 1) % (1 << 29) == 0
+    assert int(re.search(r"#define ZKP_FR9_RECIP (\d+)u", src).group(1)) == (1 << 264) // R_
+    m29 = (1 << 29) - 1
+    col = 9 * m29 * m29 + 9 * m29 * max(c["fr9_pl"])
+    assert col + (col >> 29) < 1 << 64
+    rp = F(1 << 261, R_)
+    mul = lambda a, b: a * b / rp + 1  # noqa: E731
+    tab = mul(64, 1)                                  # fr9_from_fr: 32 * (value < 2r) times R9 mod r (< r)
+    assert tab < F(14, 10)
+    # decimation in time, ten stages from a loaded / scaled element: u + v w and u - v w + 2r
+    b = tab
+    for _ in range(10):
+        v = mul(b, tab)
+        assert v < 2                                  # fr9_sub_k<2>
+        b = b + 2
+    assert b < 22 and mul(b, tab) < F(12, 10)         # the scale step brings it back
+    # decimation in frequency: reduce_weak(u + v) < 2.3, (u - v + 4r) w
+    e = F(23, 10)
+    assert e < 4 and mul(e + 4, tab) < e and 2 * e < rp
+    # pointwise: a b - c + 4r, times zinv
+    assert mul(mul(e, e) + 4, tab) < F(11, 10)
+    # back to eight words: fr9_to_fr of (element < 22 r) * coset_inv stays below 2r
+    assert mul(mul(22, tab), 1) < 2
+    # fr9_reduce_weak: q = floor(top * floor(2^264 / r) / 2^32) never exceeds floor(a / r) and misses it by less than 1.3
+    recip = (1 << 264) // R_
+    for a in (R_ - 1, 2 * R_, 5 * R_ + 12345, (1 << 261) - 1, 44 * R_ - 1):
+        q = ((a >> 232) * recip) >> 32
+        assert q <= a // R_ and a - q * R_ < 23 * R_ // 10
