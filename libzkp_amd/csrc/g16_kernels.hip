@@ -157,8 +157,9 @@ template __global__ void k_msm_dma<G1Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_msm_dma<G2Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_msm_gather<G1Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_msm_gather<G2Msm>(MsmView, uint32_t, uint32_t);
-template __global__ void k_sum_t<G1Msm>(ReduceView, uint32_t*);
-template __global__ void k_sum_t<G2Msm>(ReduceView, uint32_t*);
+static constexpr uint32_t G16_SUM_ROWS = 16;         // 32 slices per row (msm_kernel.h)
+template __global__ void k_sum_t<G1Msm, G16_SUM_ROWS>(ReduceView, uint32_t*);
+template __global__ void k_sum_t<G2Msm, G16_SUM_ROWS>(ReduceView, uint32_t*);
 template __global__ void k_g16_build_table<fq, 20>(const uint32_t*, uint32_t, uint32_t*, uint32_t);
 template __global__ void k_g16_build_table<fq2, 40>(const uint32_t*, uint32_t, uint32_t*, uint32_t);
 
@@ -207,7 +208,8 @@ void g16_launch_msm(bool g2, const MsmView& m, hipStream_t st) {
     }
 }
 void g16_launch_sum(bool g2, const ReduceView& R, uint32_t* sums, hipStream_t st) {
-    if (!g2) k_sum_t<G1Msm><<<dim3((R.rows + 63) / 64, R.ntargets), SUM_TB, 0, st>>>(R, sums);
-    else k_sum_t<G2Msm><<<dim3((R.rows + 63) / 64, R.ntargets), SUM_TB, 0, st>>>(R, sums);
+    const dim3 grid((R.rows + G16_SUM_ROWS - 1) / G16_SUM_ROWS, R.ntargets);
+    if (!g2) k_sum_t<G1Msm, G16_SUM_ROWS><<<grid, SUM_TB, 0, st>>>(R, sums);
+    else k_sum_t<G2Msm, G16_SUM_ROWS><<<grid, SUM_TB, 0, st>>>(R, sums);
 }
 void g16_launch_serialize(bool g2, const uint32_t* jac, uint32_t rows, uint8_t* out, hipStream_t st) { k_g16_serialize<<<(rows + TW - 1) / TW, TW, 0, st>>>(g2, jac, rows, out); }

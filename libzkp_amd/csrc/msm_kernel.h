@@ -136,32 +136,37 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
 // loads -- entry of step i+1, digit word of step i+2, descriptor of step i+3 -- and never waits behind one.  Kernel times were
 // within 1 % of this loop (G1 4.01 vs 4.05 ms, G2 1.70 vs 1.67 ms at 1024 membership rows): the metadata loads at the head of an
 // iteration are not what separates this kernel from the bare addition loop of tools/g1_add_rate.hip)
-// Partial sums of one target: a block owns 64 consecutive rows, its 8 waves each add every 8th chunk partial for those
-// rows (lane = row: every load is a full 256-byte coalesced segment), then a 3-level tree through LDS joins the waves.
+// Partial sums of one target.  A block owns ROWS consecutive rows and cuts the target's chunk partials into SUM_TB / ROWS slices
+// per row: every lane adds its slice's partials (every (SUM_TB / ROWS)-th chunk), then a tree through LDS joins the slices.
+// ROWS = 64 (8 slices: lane = row within a wave, every load a full 256-byte segment) for the ed25519 sums, whose additions are
+// cheap; ROWS = 16 (32 slices) for the BN254 sums, which are chains of 15-20 Jacobian additions of ~30-60 us each on a handful of
+// waves -- latency on the Groth16 prover's critical path: 32 slices make it 8 additions deep (k_sum_t<G2Msm, 16>).
 static constexpr int SUM_TB = 512;
-template <class T>
+template <class T, uint32_t ROWS = 64>
 __global__ void __launch_bounds__(SUM_TB) k_sum_t(ReduceView R, uint32_t* sums) {
-    __shared__ uint32_t lds[T::ACC_W * 256];                       // [word][4 waves x 64 lanes]
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t row = blockIdx.x * 64 + lane, target = blockIdx.y;
+    constexpr uint32_t SLICES = SUM_TB / ROWS;
+    static_assert(SUM_TB % ROWS == 0 && (SLICES & (SLICES - 1)) == 0, "slices per row: a power of two");
+    __shared__ uint32_t lds[T::ACC_W * (SUM_TB / 2)];              // [word][SLICES / 2 x ROWS]
+    const uint32_t rl = threadIdx.x % ROWS, slice = threadIdx.x / ROWS;
+    const uint32_t row = blockIdx.x * ROWS + rl, target = blockIdx.y;
     const bool active = row < R.rows;
     const uint32_t c0 = R.target_chunk_begin[target], c1 = R.target_chunk_begin[target + 1];
     typename T::Acc acc = T::identity();
     bool have = false;
     if (active) {
-        for (uint32_t c = c0 + wave; c < c1; c += 8) {
+        for (uint32_t c = c0 + slice; c < c1; c += SLICES) {
             const typename T::Acc p = T::load(R.partial, c, row, R.rows);
             acc = have ? T::add(acc, p) : p;
             have = true;
         }
     }
-    for (uint32_t stride = 4; stride >= 1; stride >>= 1) {
-        if (wave >= stride && wave < 2 * stride) T::store(lds, 0, (wave - stride) * 64 + lane, 256, acc);
+    for (uint32_t stride = SLICES / 2; stride >= 1; stride >>= 1) {
+        if (slice >= stride && slice < 2 * stride) T::store(lds, 0, (slice - stride) * ROWS + rl, SUM_TB / 2, acc);
         __syncthreads();
-        if (wave < stride) acc = T::add(acc, T::load(lds, 0, wave * 64 + lane, 256));
+        if (slice < stride) acc = T::add(acc, T::load(lds, 0, slice * ROWS + rl, SUM_TB / 2));
         __syncthreads();
     }
-    if (wave == 0 && active) {
+    if (slice == 0 && active) {
         if (R.corr) acc = T::add(acc, T::load(R.corr, target, 0, 1));
         T::store(sums, target, row, R.rows, acc);
     }
