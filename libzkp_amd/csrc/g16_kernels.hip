@@ -199,7 +199,7 @@ uint32_t g16_msm_blocks_per_cu(bool g2) { return G16_WBITS > 10 ? (g2 ? G2Msm::G
 void g16_launch_msm(bool g2, const MsmView& m, hipStream_t st) {
     const uint32_t tb = g16_msm_rows_per_block(g2);
     const uint32_t ngroups = (m.rows + tb - 1) / tb, nblocks = m.nchunks * ngroups, grid = ((nblocks + 7) / 8) * 8;
-    if constexpr (G16_WBITS > 10) {          // HBM-resident radix-2^13 tables, per-lane gathers
+    if constexpr (G16_WBITS > 10) {          // HBM-resident radix-2^14 tables, per-lane gathers
         if (!g2) k_msm_gather<G1Msm><<<grid, 256, 0, st>>>(m, ngroups, nblocks);
         else k_msm_gather<G2Msm><<<grid, 256, 0, st>>>(m, ngroups, nblocks);
     } else {                                 // radix-1024 sub-tables streamed through LDS (A/B build)

@@ -14,12 +14,14 @@
 
 namespace zkp {
 
-// Key-point tables: signed radix-2^13 digits (two 16-bit digits per word), 20 windows of 4096 affine entries per key point,
-// resident in HBM and gathered per lane (k_msm_gather): 20 mixed additions per 254-bit scalar where the LDS-streamed
-// radix-1024 tables of round 1 needed 26.  A 64-bit value needs 5 windows, a bit 1.  (ZKP_G16_WBITS=10 rebuilds the
-// radix-1024 layout: 26 windows of 512 entries, streamed through LDS by k_msm_dma -- kept for A/B measurements.)
+// Key-point tables: signed radix-2^14 digits (two 16-bit digits per word), 19 windows of 8192 affine entries per key point,
+// resident in HBM (~80 GB for the two circuits) and gathered per lane (k_msm_gather): 19 mixed additions per 254-bit scalar
+// where the LDS-streamed radix-1024 tables of round 1 needed 26.  A 64-bit value needs 5 windows, a bit 1.  Measured on the
+// 4096-op mixed batch: radix 2^13 (20 windows, 42 GB) 16.0 ms, 2^14 15.6 ms, 2^15 (17 windows, 143 GB, does not leave room
+// for two shards on one test GPU) another ~1.5 %.  (ZKP_G16_WBITS=10 rebuilds the radix-1024 layout: 26 windows
+// of 512 entries, streamed through LDS by k_msm_dma -- kept for A/B measurements; 13 / 15 build the other HBM layouts.)
 #ifndef ZKP_G16_WBITS
-#define ZKP_G16_WBITS 13
+#define ZKP_G16_WBITS 14
 #endif
 constexpr uint32_t G16_WBITS = ZKP_G16_WBITS, G16_NWIN = (254 + G16_WBITS) / G16_WBITS, G16_NENT = 1u << (G16_WBITS - 1),
                    G16_DIGW = (G16_NWIN + 1) / 2, G16_NWIN_U64 = (64 + G16_WBITS) / G16_WBITS;

@@ -78,8 +78,8 @@ __global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint
 #endif
 }
 
-// ---- HBM-resident tables, per-lane gathers (Groth16 key points).  The tables are sized for HBM, not for LDS: radix 2^13
-// needs 4096 entries per (key point, window) -- 320 KB for G1, 640 KB for G2, tens of GB per key in total -- so each lane
+// ---- HBM-resident tables, per-lane gathers (Groth16 key points).  The tables are sized for HBM, not for LDS: radix 2^14
+// needs 8192 entries per (key point, window) -- 640 KB for G1, 1.3 MB for G2, tens of GB per key in total -- so each lane
 // fetches the one entry its digit selects straight from global memory (the workgroups that share a chunk sit on one XCD and
 // walk the same sub-tables at the same time, so a good part of the entries is served from that XCD's L2).  No LDS, no
 // barrier: a workgroup is four independent waves.  Loads are software-pipelined one step ahead when the point type has the
