@@ -10,9 +10,12 @@
 using namespace zkp;
 
 template <int MAXW>
-__global__ void __launch_bounds__(256, MAXW) k9(const uint32_t* pts, uint32_t* out, int iters) {      // the nine-limb form (g1_mmadd9)
+__global__ void __launch_bounds__(256, MAXW) k9(const uint32_t* pts, uint32_t* out, int iters, int per_lane) {      // the nine-limb form (g1_mmadd9)
     g1_aff9 q[2];
-    for (int j = 0; j < 2; j++) for (int k = 0; k < 9; k++) { q[j].x.v[k] = pts[j * 20 + k]; q[j].y.v[k] = pts[j * 20 + 10 + k]; }
+    // per_lane: every lane works on its own operands (256 different point pairs), as the MSM's lanes do; otherwise all lanes hold the
+    // same limbs, which toggles far fewer bits in the multipliers -- the two cases differ in sustained clock on a power-limited chip
+    const uint32_t* src = pts + (per_lane ? 40u * threadIdx.x : 0u);
+    for (int j = 0; j < 2; j++) for (int k = 0; k < 9; k++) { q[j].x.v[k] = src[j * 20 + k]; q[j].y.v[k] = src[j * 20 + 10 + k]; }
     g1_xyzz9 acc; acc.X = q[0].x; acc.Y = q[0].y; acc.ZZ = q[1].x; acc.ZZZ = q[1].y;
     acc.X.v[0] ^= threadIdx.x & 1u;
     for (int it = 0; it < iters; it++) {
@@ -37,22 +40,25 @@ __global__ void __launch_bounds__(256, MAXW) k(const uint32_t* pts, uint32_t* ou
     uint32_t s = 0; for (int k = 0; k < 10; k++) s ^= acc.X.v[k] ^ acc.Y.v[k] ^ acc.ZZ.v[k] ^ acc.ZZZ.v[k];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-template <int MAXW, bool NINE = false> void run(int waves, const uint32_t* d_pts) {
+template <int MAXW, bool NINE = false> void run(int waves, const uint32_t* d_pts, int per_lane = 0) {
     const int blocks = 256 * waves, iters = 400;
     uint32_t* d; (void)hipMalloc(&d, (size_t)blocks * 256 * 4);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     float best = 1e30f;
-    for (int r = 0; r < 4; r++) { (void)hipEventRecord(e0); if (NINE) k9<MAXW><<<blocks, 256>>>(d_pts, d, iters); else k<MAXW><<<blocks, 256>>>(d_pts, d, iters); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms; }
+    for (int r = 0; r < 4; r++) { (void)hipEventRecord(e0); if (NINE) k9<MAXW><<<blocks, 256>>>(d_pts, d, iters, per_lane); else k<MAXW><<<blocks, 256>>>(d_pts, d, iters); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms; }
     const double adds = (double)blocks * 256 * iters;
-    printf("{\"form\": \"%s\", \"launch_bounds_waves\": %d, \"waves_per_simd\": %d, \"ms\": %.3f, \"g_adds_per_s\": %.2f, \"t_mad_per_s\": %.2f}\n", NINE ? "9x29" : "10x26", MAXW, waves, best, adds / (best * 1e-3) / 1e9, adds * (NINE ? 1629 : 1810) / (best * 1e-3) / 1e12);
+    printf("{\"form\": \"%s\", \"operands\": \"%s\", \"launch_bounds_waves\": %d, \"waves_per_simd\": %d, \"ms\": %.3f, \"g_adds_per_s\": %.2f, \"t_mad_per_s\": %.2f}\n", NINE ? "9x29" : "10x26", per_lane ? "per lane" : "same in every lane", MAXW, waves, best, adds / (best * 1e-3) / 1e9, adds * (NINE ? 1629 : 1810) / (best * 1e-3) / 1e12);
     (void)hipFree(d);
 }
 int main() {
-    uint32_t h[40]; for (int k = 0; k < 40; k++) h[k] = 0x1234567u * (k + 1) & 0x3ffffffu;      // < 2^26: carried in either form
+    static uint32_t h[40 * 256]; uint64_t s = 0x9E3779B97F4A7C15ull;
+    for (int k = 0; k < 40; k++) h[k] = 0x1234567u * (k + 1) & 0x3ffffffu;      // < 2^26: carried in either form
+    for (int k = 40; k < 40 * 256; k++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[k] = (uint32_t)s & 0x3ffffffu; }
     uint32_t* d_pts; (void)hipMalloc(&d_pts, sizeof h); (void)hipMemcpy(d_pts, h, sizeof h, hipMemcpyHostToDevice);
     for (int w : {1, 2, 3}) run<3>(w, d_pts);            // 168-VGPR budget, as the MSM kernel
     for (int w : {2, 4}) run<4>(w, d_pts);               // 128-VGPR budget
     for (int w : {1, 2}) run<2>(w, d_pts);               // 256-VGPR budget
-    for (int w : {1, 2, 3}) run<3, true>(w, d_pts);      // nine 29-bit limbs: 7 x 162 + 2 x 126 + 243 = 1 629 multiply-adds per addition
+    for (int w : {1, 2, 3}) run<3, true>(w, d_pts);
+    for (int w : {2, 3}) run<3, true>(w, d_pts, 1);      // operands that differ from lane to lane      // nine 29-bit limbs: 7 x 162 + 2 x 126 + 243 = 1 629 multiply-adds per addition
     return 0;
 }
