@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE: host build of the BN254 device headers for the no-GPU test tier.
 #include "../../libzkp_amd/csrc/bn254_pairing.h"
+#include "../../libzkp_amd/csrc/bn254_fr9.h"
 #include <string.h>
 using namespace zkp;
 
@@ -102,6 +103,19 @@ void emul_g2_xyzz9_chain(const uint32_t o[32], const uint32_t* pts, const int* s
     }
     *max_limb = mx;
     g2_serialize(out, jac_from_g2_xyzz9(acc));
+}
+// Fr on nine 29-bit limbs (bn254_fr9.h) through its conversions: out0 = a b, out1 = a - b (fr9_sub_k<2> on products < 2r), out2 = the
+// weak reduction of a + 20 b (raw in, raw out)
+void emul_fr9_ops(const uint32_t a[8], const uint32_t b[8], uint32_t mul[8], uint32_t sub[8], uint32_t red[8]) {
+    const fr x = fp_from_raw<FrParams>(a), y = fp_from_raw<FrParams>(b);
+    const fr9 x9 = fr9_from_fr(x), y9 = fr9_from_fr(y);
+    fp_to_raw(mul, fr9_to_fr<FrParams>(fr9_mul(x9, y9)));
+    fp_to_raw(sub, fr9_to_fr<FrParams>(fr9_sub_k<2>(x9, y9)));
+    fr9 acc = x9; for (int i = 0; i < 20; i++) acc = fr9_add(acc, y9);          // < 30 r, unreduced
+    const fr9 w = fr9_reduce_weak(acc);
+    uint32_t top = 0; for (int i = 0; i < 9; i++) top |= (i < 8 && w.v[i] >> 29) ? 1u : 0u;
+    fp_to_raw(red, fr9_to_fr<FrParams>(w));
+    red[7] |= top << 31;                                                        // a limb of the reduced value out of range would show here
 }
 void emul_fr_op(int op, const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) { fp_op<FrParams>(op, a, b, out); }
 void emul_fr_from_wide(const uint32_t w[16], uint32_t out[8]) { fp_to_raw(out, fp_from_wide<FrParams>(w)); }

@@ -49,6 +49,11 @@ def test_fields(libs):
         assert I(out) == a * c % b.P
         lib.emul_fq9_ops(W(a), W(c), out, o2, o3)
         assert I(out) == a * a % b.P and I(o2) == (a * a - a * c) % b.P and I(o3) == 3 * (a - c) % b.P
+    vals = [0, 1, 2, b.R - 1, b.R - 2, (b.R - 1) // 2, 2**253, 2**255, 2**256 - 1] + [rnd.randrange(b.R) for _ in range(150)]
+    for i, a in enumerate(vals):                       # Fr on nine limbs (bn254_fr9.h, the QAP step's form)
+        c = vals[(i * 7 + 3) % len(vals)]
+        lib.emul_fr9_ops(W(a), W(c), out, o2, o3)
+        assert I(out) == a * c % b.R and I(o2) == (a - c) % b.R and I(o3) == (a + 20 * c) % b.R
     for x in [0, 2**512 - 1] + [rnd.randrange(2**512) for _ in range(20)]:
         lib.emul_fr_from_wide(W(x, 16), out)
         assert I(out) == x % b.R
