@@ -116,7 +116,15 @@ def test_batch_check_and_per_job_check_agree(hip, oracle_c, monkeypatch):
             monkeypatch.delenv(k)
 
 
-def test_threshold_verification_matches_oracle(hip, oracle_c):
+@pytest.fixture(params=["default", "batch-check-first"])
+def verify_mode(request, monkeypatch):
+    """the Bulletproofs verifiers as they run by default at these sizes (per-job check) and with the whole-batch check forced on"""
+    if request.param == "batch-check-first":
+        monkeypatch.setenv("ZKP_HIP_BATCH_VERIFY_MIN", "1")
+    return request.param
+
+
+def test_threshold_verification_matches_oracle(hip, oracle_c, verify_mode):
     import ctypes
     import libzkp_amd as z
     rng = np.random.default_rng(17)
@@ -142,7 +150,7 @@ def test_threshold_verification_matches_oracle(hip, oracle_c):
     assert not z.verify_threshold(z.prove_range(5, 0, 10), 0)
 
 
-def test_consistency_verification_matches_oracle(hip, oracle_c):
+def test_consistency_verification_matches_oracle(hip, oracle_c, verify_mode):
     import ctypes
     import libzkp_amd as z
     rng = np.random.default_rng(29)
