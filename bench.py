@@ -282,8 +282,11 @@ def main():
                                              "carries, masks and loads share the same issue slots: a pure product chain reaches 75 % of it, the bare addition loop "
                                              "(profiles/r02_g1_add_rate.jsonl) 75 %); launch durations are taken while the other variants' kernels share the GPU"},
             "other_msm_kernels": {
-                "k_msm_gather<G2Msm>": {"avg_launch_ms": g2[0] / max(1, g2[1]), "launches": g2[1], "ms_per_step": g2[0] / max(1, args.steps)},
+                "k_msm_gather<G2Msm>": {"avg_launch_ms": g2[0] / max(1, g2[1]), "launches": g2[1], "ms_per_step": g2[0] / max(1, args.steps),
+                                        "point_additions_per_step": g2[2] / max(1, args.steps), "g_additions_per_s": g2[2] / (g2[0] * 1e-3) / 1e9 if g2[0] > 0 else None,
+                                        "mads_per_point_addition": 4536},
                 "k_msm_dma<EdMsm>": {"avg_launch_ms": ed[0] / max(1, ed[1]), "launches": ed[1], "ms_per_step": ed[0] / max(1, args.steps),
+                                     "point_additions_per_step": ed[2] / max(1, args.steps), "g_additions_per_s": ed[2] / (ed[0] * 1e-3) / 1e9 if ed[0] > 0 else None,
                                      "valu_frac": (ed[2] * MADS_PER_ED_MADD / (ed[0] * 1e-3) / 1e12 / MAD_ISSUE_T) if ed[0] > 0 else None}},
         }
         res.update(extra)

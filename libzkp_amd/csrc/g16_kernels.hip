@@ -10,9 +10,9 @@ struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq>(); }
 #ifndef ZKP_G1_GATHER_WAVES
 #define ZKP_G1_GATHER_WAVES 3
-#define ZKP_G1_GATHER_PREFETCH 1
+#define ZKP_G1_GATHER_PREFETCH 2
 #endif
-    static constexpr uint32_t GATHER_WAVES = ZKP_G1_GATHER_WAVES; static constexpr bool GATHER_PREFETCH = ZKP_G1_GATHER_PREFETCH != 0;      // k_msm_gather: 3 waves/SIMD, entries one step ahead
+    static constexpr uint32_t GATHER_WAVES = ZKP_G1_GATHER_WAVES; static constexpr int GATHER_PREFETCH = ZKP_G1_GATHER_PREFETCH;      // k_msm_gather: 3 waves/SIMD, entries two steps ahead
     // the gather loop accumulates in XYZZ coordinates on nine 29-bit limbs (bn254_g.h: g1_mmadd9); the key tables hold their
     // entries in that form (x: words 0..8, y: words 9..17 of the 20-word entry; k_g16_build_table)
     using GAcc = g1_xyzz9;
@@ -39,7 +39,7 @@ struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
     static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int16_t)(word >> (16 * (w & 1u))); }
     using Acc = g2_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq2>(); }
-    static constexpr uint32_t GATHER_WAVES = 2; static constexpr bool GATHER_PREFETCH = false;     // k_msm_gather: 256 VGPRs are taken by the addition itself
+    static constexpr uint32_t GATHER_WAVES = 2; static constexpr int GATHER_PREFETCH = 0;     // k_msm_gather: the addition itself takes 243 VGPRs, entries are fetched at use
     // the gather loop: XYZZ coordinates over Fq2 on nine 29-bit limbs (bn254_g.h: g2_mmadd9); table entries in that form
     // (x.c0, x.c1, y.c0, y.c1 at words 0, 9, 18, 27 of the 40-word entry)
     using GAcc = g2_xyzz9;

@@ -82,9 +82,9 @@ __global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint
 // needs 8192 entries per (key point, window) -- 640 KB for G1, 1.3 MB for G2, tens of GB per key in total -- so each lane
 // fetches the one entry its digit selects straight from global memory (the workgroups that share a chunk sit on one XCD and
 // walk the same sub-tables at the same time, so a good part of the entries is served from that XCD's L2).  No LDS, no
-// barrier: a workgroup is four independent waves.  Loads are software-pipelined one step ahead when the point type has the
-// registers for it (T::GATHER_PREFETCH): the next entry's 16-byte pieces are issued before the current addition starts and
-// consumed ~10 us later; the digit word that selects them was fetched one step earlier still.
+// barrier: a workgroup is four independent waves.  Loads are software-pipelined when the point type has the registers for it
+// (T::GATHER_PREFETCH = number of steps of lead, 0 / 1 / 2): an entry's 16-byte pieces are issued one or two additions (~10 us each)
+// before the addition that consumes them; the digit word that selects them is fetched earlier still.
 template <class T>
 __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, uint32_t ngroups, uint32_t nblocks) {
     constexpr uint32_t V4 = T::AFF_W / 4;
@@ -112,22 +112,38 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
     int32_t d = T::digit(dw, w);
     uint4 cur[V4], nxt[V4];
     fetch(cur, s, w, d);
-    while (left) {
-        const uint32_t nwin = m.slot_nwin[s];
-        uint32_t ns = s, nw = w + 1;
-        if (nw == nwin) { ns = s + 1; nw = 0; }
-        int32_t dn = 0;
-        if (left > 1) {
-            if ((nw % T::DIG_PER_WORD) == 0) dw = digit_word(ns, nw);
-            dn = T::digit(dw, nw);
-            if constexpr (T::GATHER_PREFETCH) fetch(nxt, ns, nw, dn);
+    if constexpr (T::GATHER_PREFETCH == 2) {
+        // entries TWO steps ahead (the G1 loop has the registers): a wave waits for the slowest of its 64 x 5 scattered loads, and with
+        // one step of lead (~10 us) the tail of the HBM latency distribution still showed (10 % of the launch)
+        auto advance = [&](uint32_t& ps, uint32_t& pw) { if (++pw == m.slot_nwin[ps]) { ps++; pw = 0; } };
+        uint4 nx2[V4];
+        uint32_t s1 = s, w1 = w, s2, w2; int32_t d1 = 0, d2 = 0;
+        if (left > 1) { advance(s1, w1); if ((w1 % T::DIG_PER_WORD) == 0) dw = digit_word(s1, w1); d1 = T::digit(dw, w1); fetch(nxt, s1, w1, d1); }
+        s2 = s1; w2 = w1;
+        while (left) {
+            if (left > 2) { advance(s2, w2); if ((w2 % T::DIG_PER_WORD) == 0) dw = digit_word(s2, w2); d2 = T::digit(dw, w2); fetch(nx2, s2, w2, d2); }
+            if (d != 0) acc = T::accumulate_entry(acc, d, reinterpret_cast<const uint32_t*>(cur));
+            ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) { cur[k] = nxt[k]; nxt[k] = nx2[k]; }
+            d = d1; d1 = d2; d2 = 0; left--;
         }
-        if (d != 0) acc = T::accumulate_entry(acc, d, reinterpret_cast<const uint32_t*>(cur));
-        if (left > 1) {
-            if constexpr (T::GATHER_PREFETCH) { ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) cur[k] = nxt[k]; }
-            else fetch(cur, ns, nw, dn);
+    } else {
+        while (left) {
+            const uint32_t nwin = m.slot_nwin[s];
+            uint32_t ns = s, nw = w + 1;
+            if (nw == nwin) { ns = s + 1; nw = 0; }
+            int32_t dn = 0;
+            if (left > 1) {
+                if ((nw % T::DIG_PER_WORD) == 0) dw = digit_word(ns, nw);
+                dn = T::digit(dw, nw);
+                if constexpr (T::GATHER_PREFETCH != 0) fetch(nxt, ns, nw, dn);
+            }
+            if (d != 0) acc = T::accumulate_entry(acc, d, reinterpret_cast<const uint32_t*>(cur));
+            if (left > 1) {
+                if constexpr (T::GATHER_PREFETCH != 0) { ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) cur[k] = nxt[k]; }
+                else fetch(cur, ns, nw, dn);
+            }
+            s = ns; w = nw; d = dn; left--;
         }
-        s = ns; w = nw; d = dn; left--;
     }
     if (active) T::store(m.partial, chunk, row, m.rows, T::from_gather(acc));
 }
