@@ -209,7 +209,7 @@ def main():
 
     extra = {}
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-    if rank == 0 and not args.no_extra_legs and not under_profiler:     # a profile of this command holds the timed steps only
+    if world == 1 and not args.no_extra_legs and not under_profiler:    # N = 1 only; a profile of this command holds the timed steps only
         def timed(f, reps):
             f()
             ts = []
@@ -303,7 +303,7 @@ def main():
                                      "valu_frac": (ed[2] * MADS_PER_ED_MADD / (ed[0] * 1e-3) / 1e12 / MAD_ISSUE_T) if ed[0] > 0 else None}},
         }
         res.update(extra)
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:                 # the contract: rank 0 at N = 1 only
             threads = min(len(os.sched_getaffinity(0)), 32)
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample, threads)
         print(json.dumps(res), flush=True)
