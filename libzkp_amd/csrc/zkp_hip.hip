@@ -886,8 +886,9 @@ void zkp_hip_shutdown(void) {
 }
 
 void zkp_hip_profile_enable(int on) {
-    Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu);
-    for (Device* d : R.shards) { std::lock_guard<std::mutex> dl(d->mu); d->profiling = on != 0; }
+    std::vector<Device*> shards;      // (the registry lock is not held while a shard's is taken: Bind::open takes them in the other order)
+    { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); shards = R.shards; }
+    for (Device* d : shards) { std::lock_guard<std::mutex> dl(d->mu); d->profiling = on != 0; }
 }
 
 // accumulated over all shards

@@ -253,3 +253,69 @@ def test_two_batches_in_flight_on_one_shard():
         assert L.zkp_hip_batch_fetch(h, P(out), cap, P(o2), P(s2)) == rc
         assert (o2 == off).all() and (s2 == st).all() and out[:int(o2[-1])].tobytes() == b"".join(got)
         L.zkp_hip_batch_free(h)
+
+
+def test_fewer_ops_than_shards_and_empty_staged_batch():
+    """A shard that owns no op still reports out_off[0] = 0 (two shards, one op), and an empty staged batch proves and
+    fetches as nothing."""
+    from libzkp_amd import _native
+    L = _lib()
+    one = tuple(x[:1].copy() if i == 0 else x for i, x in enumerate(wl.mixed_ops(4, 77)))         # one range op
+    ref = _run(L, one[0], one[1], one[2][:32].copy())
+    h = ctypes.c_void_p()
+    assert L.zkp_hip_batch_stage(0, None, None, None, ctypes.byref(h)) == 0, _native.last_error()
+    assert L.zkp_hip_batch_prove(h) == 0, _native.last_error()
+    off = np.full(1, 99, dtype=np.uint64); out = np.zeros(8, dtype=np.uint8)
+    assert L.zkp_hip_batch_fetch(h, P(out), 8, P(off), None) == 0, _native.last_error()
+    assert int(off[0]) == 0
+    L.zkp_hip_batch_free(h)
+    L = _lib(devices=[0, 0])
+    try:
+        for nops in (1, 3):
+            ops, lists, seeds = wl.mixed_ops(4, 77)
+            ops, seeds = ops[:nops].copy(), seeds[:32 * nops].copy()
+            rc, got, st, off = _run(L, ops, lists, seeds)
+            assert rc == 0 and not st.any() and int(off[-1]) == sum(len(g) for g in got)
+            assert got[0] == ref[1][0]
+    finally:
+        L.zkp_hip_shutdown()
+        _lib()
+
+
+def test_per_variant_groth16_call_while_a_batch_is_in_flight():
+    """zkp_hip_prove_equality_batch / _membership_batch use lane 0's Groth16 workspace; a batch launched with
+    zkp_hip_batch_prove_async on that lane may still be running: the second user waits for the first (stream-ordered)."""
+    from libzkp_amd import _native
+    L = _lib()
+    b = wl.mixed_ops(512, 41)
+    want = _run(L, *b)
+    e_ops, e_lists, e_seeds = wl.equality_ops(300, 43)
+    want_e = _per_variant(L, e_ops, e_lists, e_seeds)
+    h = ctypes.c_void_p()
+    assert L.zkp_hip_batch_stage(len(b[0]), P(b[0]), P(b[1]), P(b[2]), ctypes.byref(h)) == 0, _native.last_error()
+    for rnd in range(2):
+        assert L.zkp_hip_batch_prove_async(h) == 0, _native.last_error()
+        got_e = _per_variant(L, e_ops, e_lists, e_seeds)             # while the batch runs
+        assert L.zkp_hip_batch_wait(h) == 0
+        assert got_e == want_e
+        n = len(b[0]); cap = int(L.zkp_hip_batch_max_bytes(h))
+        out = np.zeros(cap, dtype=np.uint8); o2 = np.zeros(n + 1, dtype=np.uint64); s2 = np.zeros(n, dtype=np.int32)
+        assert L.zkp_hip_batch_fetch(h, P(out), cap, P(o2), P(s2)) == 0
+        assert out[:int(o2[-1])].tobytes() == b"".join(want[1])
+    L.zkp_hip_batch_free(h)
+
+
+def test_missing_key_fails_before_anything_is_enqueued_and_a_retry_works():
+    from libzkp_amd import _native
+    L = _lib()
+    b = wl.mixed_ops(64, 51)
+    want = _run(L, *b)
+    L.zkp_hip_shutdown()
+    _native.check(L.zkp_hip_init(0), "zkp_hip_init")                 # no keys in this life of the shard
+    n = len(b[0]); cap = wl.max_output_bytes(b[0])
+    out = np.zeros(cap, dtype=np.uint8); off = np.zeros(n + 1, dtype=np.uint64); st = np.zeros(n, dtype=np.int32)
+    assert L.zkp_hip_process_batch(n, P(b[0]), P(b[1]), P(b[2]), P(out), cap, P(off), P(st)) == -3
+    assert "no proving key" in _native.last_error()
+    L = _lib()
+    got = _run(L, *b)
+    assert got[1] == want[1]
