@@ -188,6 +188,28 @@ ZKP_HD inline fq fq_reslice(const fq9& c) {                     // c carried9
     return r;
 }
 ZKP_HD inline fq9 fq9_from_fq(const fq& a) { return fq9_reslice(fq_dbl(a)); }          // value < 3p
+// ---- key-table form: a carried9 value below 2^256 (table entries are < 2.4 p < 2^255) as eight 32-bit words -- the same integer,
+// re-sliced -- so that a G1 entry (x, y) is 64 bytes and a G2 entry 128: one half / one whole 128-byte line per gather instead of
+// the 1.6 lines an 80-byte slot of nine-limb coordinates straddled.  Unpacking is one funnel shift and one mask per limb.
+ZKP_HD inline void fq9_pack8(uint32_t w[8], const fq9& a) {
+    ZKP_UNROLL for (int k = 0; k < 8; k++) {
+        const int bit = 32 * k, i = bit / 29, sh = bit % 29;
+        uint64_t x = (uint64_t)a.v[i] >> sh;
+        if (i + 1 < 9) x |= (uint64_t)a.v[i + 1] << (29 - sh);
+        if (i + 2 < 9) x |= (uint64_t)a.v[i + 2] << (58 - sh);
+        w[k] = (uint32_t)x;
+    }
+}
+ZKP_HD inline fq9 fq9_unpack8(const uint32_t w[8]) {
+    fq9 r;
+    ZKP_UNROLL for (int j = 0; j < 9; j++) {
+        const int bit = 29 * j, i = bit / 32, sh = bit % 32;
+        uint64_t x = (uint64_t)w[i] >> sh;
+        if (i + 1 < 8) x |= (uint64_t)w[i + 1] << (32 - sh);
+        r.v[j] = j < 8 ? ((uint32_t)x & ZKP_FQ9_MASK) : (uint32_t)x;
+    }
+    return r;
+}
 ZKP_HD inline fq fq9_to_fq(const fq9& a) {                                                   // value < a / 169 + p, then < 3p
     fq9 c; ZKP_UNROLL for (int i = 0; i < 9; i++) c.v[i] = fq9_r10(i);
     return fq_reduce_weak(fq_reslice(fq9_mul(a, c)));

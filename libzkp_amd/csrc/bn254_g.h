@@ -270,6 +270,77 @@ template <class F> ZKP_HD inline Jac<F> jac_mul_raw(const Jac<F>& p, const uint3
     return acc;
 }
 
+// ---- GLV split for G1 (s*A and r*B1 of the Groth16 C element).  BN254 has the endomorphism phi(x, y) = (beta x, y) = lambda (x, y)
+// with beta^2 + beta + 1 = 0 in Fq and lambda^2 + lambda + 1 = 0 in Fr, so k P = k1 P + k2 phi(P) with |k1|, |k2| < 2^128
+// (k = k1 + k2 lambda mod r): two half-length multiplications on two lanes instead of one 254-bit ladder on one -- a lone wave gets
+// half of a SIMD's multiply-add rate however its instructions are arranged (profiles/r02_mad_ilp.txt), so latency only falls by
+// spreading a proof over more lanes.  Lattice basis of {(a, b): a + b lambda = 0 mod r} from the extended Euclidean algorithm on
+// (r, lambda): v1 = (A1, -NB1), v2 = (A2, B2), det = r; c1 = floor(k G1 / 2^256) ~ B2 k / r, c2 = floor(k G2 / 2^256) ~ NB1 k / r,
+// k1 = k - c1 A1 - c2 A2, k2 = c1 NB1 - c2 B2, both taken mod 2^160 as two's-complement numbers (exhaustively sampled in
+// tests/test_emul_groth16.py: magnitudes stay below 2^128 with the floor quotients).
+template <int NA, int NB, int NO> ZKP_HD inline void mp_mul_lo(uint32_t* out, const uint32_t* a, const uint32_t* b) {      // low NO words of a * b
+    uint64_t acc = 0, hi = 0;
+    ZKP_UNROLL for (int k = 0; k < NO; k++) {
+        ZKP_UNROLL for (int i = 0; i < NA; i++) {
+            const int j = k - i;
+            if (j < 0 || j >= NB) continue;
+            const uint64_t t = (uint64_t)a[i] * b[j];
+            acc += (uint32_t)t; hi += t >> 32;
+        }
+        out[k] = (uint32_t)acc;
+        acc = (acc >> 32) + (uint32_t)hi; hi >>= 32;
+    }
+}
+struct glv_half { uint32_t mag[4]; bool neg; };
+ZKP_HD inline glv_half glv_from_160(const uint32_t w[5]) {       // two's complement mod 2^160, |value| < 2^128
+    glv_half h; h.neg = (w[4] >> 31) != 0;
+    uint32_t c = h.neg ? 1u : 0u;
+    ZKP_UNROLL for (int i = 0; i < 4; i++) { const uint32_t x = h.neg ? ~w[i] : w[i]; const uint32_t t = x + c; c = (c && t == 0) ? 1u : 0u; h.mag[i] = t; }
+    return h;
+}
+ZKP_HD inline void fr_glv_split(const uint32_t k[8], glv_half& h1, glv_half& h2) {
+    const uint32_t G1[3] = {0xc7e0b3d7u, 0xd91d232eu, 0x00000002u}, G2[5] = {0x391eb18du, 0x7a7bd9d4u, 0xa773d2cfu, 0x4ccef014u, 0x00000002u};
+    const uint32_t A1[2] = {0x94d213e3u, 0x89d32568u}, A2[4] = {0x1221250bu, 0x0be4e154u, 0xeeb859fdu, 0x6f4d8248u};
+    const uint32_t NB1[4] = {0x7d4f1128u, 0x8211bbebu, 0xeeb859fcu, 0x6f4d8248u}, B2[2] = {0x94d213e3u, 0x89d32568u};
+    uint32_t t1[11], t2[13];
+    mp_mul_lo<8, 3, 11>(t1, k, G1); mp_mul_lo<8, 5, 13>(t2, k, G2);
+    const uint32_t* c1 = t1 + 8;      // 3 words
+    const uint32_t* c2 = t2 + 8;      // 5 words
+    uint32_t p11[5], p22[5], p12[5], p21[5];
+    mp_mul_lo<3, 2, 5>(p11, c1, A1); mp_mul_lo<5, 4, 5>(p22, c2, A2); mp_mul_lo<3, 4, 5>(p12, c1, NB1); mp_mul_lo<5, 2, 5>(p21, c2, B2);
+    uint32_t k1[5], k2[5]; int64_t b1 = 0, b2 = 0;
+    ZKP_UNROLL for (int i = 0; i < 5; i++) {
+        b1 += (int64_t)k[i] - (int64_t)p11[i] - (int64_t)p22[i]; k1[i] = (uint32_t)b1; b1 >>= 32;
+        b2 += (int64_t)p12[i] - (int64_t)p21[i]; k2[i] = (uint32_t)b2; b2 >>= 32;
+    }
+    h1 = glv_from_160(k1); h2 = glv_from_160(k2);
+}
+ZKP_HD inline fq fq_glv_beta() {       // beta with phi(P) = lambda P for the lambda of fr_glv_split
+    const uint32_t w[8] = {0x77fffffeu, 0x57634731u, 0xacdb5c4fu, 0xd4f263f1u, 0xa0d48bacu, 0x59e26bceu, 0x00000000u, 0x00000000u};
+    return fq_from_raw(w);
+}
+// (+-mag) * p for a magnitude below 2^128: signed 4-bit windows (33 digits in [-8, 8]) over the table p, 2p, ..., 8p
+template <class F> ZKP_HD inline Jac<F> jac_mul_u128_signed(const Jac<F>& p, const uint32_t mag[4], bool neg) {
+    Jac<F> tbl[8];
+    tbl[0] = p; tbl[1] = jac_dbl(p);
+    for (int i = 2; i < 8; i++) tbl[i] = jac_add(tbl[i - 1], p);
+    int dig[33]; int carry = 0;
+    for (int i = 0; i < 32; i++) {
+        int v = (int)((mag[i >> 3] >> ((i & 7) * 4)) & 15u) + carry;
+        carry = v > 8 ? 1 : 0; if (carry) v -= 16;
+        dig[i] = v;
+    }
+    dig[32] = carry;
+    Jac<F> acc = jac_infinity<F>();
+    for (int i = 32; i >= 0; i--) {
+        if (i != 32) acc = jac_dbl(jac_dbl(jac_dbl(jac_dbl(acc))));
+        const int d = dig[i];
+        if (d > 0) acc = jac_add(acc, tbl[d - 1]);
+        else if (d < 0) acc = jac_add(acc, jac_neg(tbl[-d - 1]));
+    }
+    return neg ? jac_neg(acc) : acc;
+}
+
 // (x, y) affine; returns false for the point at infinity
 template <class F> ZKP_HD inline bool jac_to_aff(Aff<F>& out, const Jac<F>& p) {
     if (jac_is_inf(p)) return false;

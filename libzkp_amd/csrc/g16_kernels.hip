@@ -13,13 +13,14 @@ struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b
 #define ZKP_G1_GATHER_PREFETCH 2
 #endif
     static constexpr uint32_t GATHER_WAVES = ZKP_G1_GATHER_WAVES; static constexpr int GATHER_PREFETCH = ZKP_G1_GATHER_PREFETCH;      // k_msm_gather: 3 waves/SIMD, entries two steps ahead
-    // the gather loop accumulates in XYZZ coordinates on nine 29-bit limbs (bn254_g.h: g1_mmadd9); the key tables hold their
-    // entries in that form (x: words 0..8, y: words 9..17 of the 20-word entry; k_g16_build_table)
+    // the gather loop accumulates in XYZZ coordinates on nine 29-bit limbs (bn254_g.h: g1_mmadd9); the key tables hold the
+    // nine-limb coordinates packed into eight words each (fq9_pack8): a 64-byte, 64-byte-aligned entry x | y (k_g16_build_table)
+    static constexpr uint32_t GATHER_W = 16;
     using GAcc = g1_xyzz9;
     static __device__ __forceinline__ GAcc to_gather(const g1_jac& a) { return xyzz9_from_jac(a); }
     static __device__ __forceinline__ g1_jac from_gather(const GAcc& a) { return jac_from_xyzz9(a); }
     static __device__ __forceinline__ GAcc accumulate_entry(const GAcc& acc, int32_t d, const uint32_t* e) {
-        g1_aff9 q; ZKP_UNROLL for (int k = 0; k < 9; k++) { q.x.v[k] = e[k]; q.y.v[k] = e[9 + k]; }
+        g1_aff9 q{fq9_unpack8(e), fq9_unpack8(e + 8)};
         q.y = fq9_select(d < 0, fq9_neg_k<4>(q.y), q.y);                 // entries are < 3p
         return g1_mmadd9(acc, q);
     }
@@ -40,13 +41,14 @@ struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
     using Acc = g2_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq2>(); }
     static constexpr uint32_t GATHER_WAVES = 2; static constexpr int GATHER_PREFETCH = 0;     // k_msm_gather: the addition itself takes 243 VGPRs, entries are fetched at use
-    // the gather loop: XYZZ coordinates over Fq2 on nine 29-bit limbs (bn254_g.h: g2_mmadd9); table entries in that form
-    // (x.c0, x.c1, y.c0, y.c1 at words 0, 9, 18, 27 of the 40-word entry)
+    // the gather loop: XYZZ coordinates over Fq2 on nine 29-bit limbs (bn254_g.h: g2_mmadd9); table entries are the four
+    // coordinates x.c0, x.c1, y.c0, y.c1 packed into eight words each: 128 bytes, one cache line
+    static constexpr uint32_t GATHER_W = 32;
     using GAcc = g2_xyzz9;
     static __device__ __forceinline__ GAcc to_gather(const g2_jac& a) { return g2_xyzz9_from_jac(a); }
     static __device__ __forceinline__ g2_jac from_gather(const GAcc& a) { return jac_from_g2_xyzz9(a); }
     static __device__ __forceinline__ GAcc accumulate_entry(const GAcc& acc, int32_t d, const uint32_t* e) {
-        g2_aff9 q; ZKP_UNROLL for (int k = 0; k < 9; k++) { q.x.c0.v[k] = e[k]; q.x.c1.v[k] = e[9 + k]; q.y.c0.v[k] = e[18 + k]; q.y.c1.v[k] = e[27 + k]; }
+        const g2_aff9 q{fq2_9{fq9_unpack8(e), fq9_unpack8(e + 8)}, fq2_9{fq9_unpack8(e + 16), fq9_unpack8(e + 24)}};
         return g2_mmadd9(acc, q, d < 0);
     }
     static __device__ __forceinline__ Acc accumulate_entry(const Acc& acc, int32_t d, const uint32_t* e) {      // ten-limb entries (LDS A/B build)
@@ -116,7 +118,9 @@ __global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, u
     Jac<F> q = jac_from_aff(base);
     for (uint32_t i = 0; i < G16_WBITS * win; i++) q = jac_dbl(q);
     Jac<F> acc = q;
-    uint32_t* dst = table + ((size_t)slot * G16_NWIN + win) * G16_NENT * AFF_W;
+    constexpr uint32_t NC = AFF_W / 10;                      // Fq coordinates per entry
+    const uint32_t OW = fmt9 ? 8 * NC : AFF_W;             // words per stored entry
+    uint32_t* dst = table + ((size_t)slot * G16_NWIN + win) * G16_NENT * OW;
     for (uint32_t e0 = 0; e0 < G16_NENT; e0 += BATCH) {
         Jac<F> pts[BATCH]; F zp[BATCH];
         for (uint32_t k = 0; k < BATCH; k++) {
@@ -130,12 +134,10 @@ __global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, u
             const F zi2 = f_sq(zi);
             Aff<F> a; a.x = f_mul(pts[k].X, zi2); a.y = f_mul(pts[k].Y, f_mul(zi2, zi));
             const uint32_t* ax = reinterpret_cast<const uint32_t*>(&a.x); const uint32_t* ay = reinterpret_cast<const uint32_t*>(&a.y);
-            uint32_t* o = dst + (size_t)(e0 + k) * AFF_W;
-            if (fmt9) {                                            // the MSM loops' form: nine 29-bit limbs per Fq coordinate, < 3p
+            uint32_t* o = dst + (size_t)(e0 + k) * OW;
+            if (fmt9) {                                            // the MSM loops' form: nine 29-bit limbs per Fq coordinate (< 2.4 p), packed
                 const fq* c = reinterpret_cast<const fq*>(&a);     // x then y (G1) / x.c0, x.c1, y.c0, y.c1 (G2)
-                constexpr uint32_t NC = AFF_W / 10;
-                for (uint32_t t = 0; t < NC; t++) { const fq9 v = fq9_from_fq(c[t]); for (uint32_t j = 0; j < 9; j++) o[9 * t + j] = v.v[j]; }
-                for (uint32_t j = 9 * NC; j < AFF_W; j++) o[j] = 0;
+                for (uint32_t t = 0; t < NC; t++) fq9_pack8(o + 8 * t, fq9_from_fq(c[t]));
                 continue;
             }
             for (uint32_t j = 0; j < FW; j++) { o[j] = ax[j]; o[FW + j] = ay[j]; }
@@ -174,7 +176,7 @@ hipError_t g16_launch_qap(const G16View& V, const G16Circuit& C, hipStream_t st)
     return hipSuccess;
 }
 void g16_launch_cparts(const G16View& V, const uint32_t* sum_g1, uint32_t* tmp_g1, hipStream_t st) {
-    k_g16_cparts<<<dim3((V.rows + TW - 1) / TW, 2), TW, 0, st>>>(V, sum_g1, tmp_g1);
+    k_g16_cparts<<<dim3((V.rows + TW - 1) / TW, G16_CPARTS), TW, 0, st>>>(V, sum_g1, tmp_g1);
 }
 void g16_launch_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* sum_g2, const uint32_t* tmp_g1, hipStream_t st) {
     k_g16_final<<<dim3((V.rows + TW - 1) / TW, 3), TW, 0, st>>>(V, sum_g1, sum_g2, tmp_g1);
@@ -193,6 +195,9 @@ hipError_t g16_prepare_device() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<G1Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<G1Msm>());
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<G2Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<G2Msm>());
+}
+uint32_t g16_table_entry_words(bool g2, bool msm_form) {
+    return (msm_form && G16_WBITS > 10) ? (g2 ? G2Msm::GATHER_W : G1Msm::GATHER_W) : (g2 ? G2Msm::AFF_W : G1Msm::AFF_W);
 }
 uint32_t g16_msm_rows_per_block(bool g2) { return G16_WBITS > 10 ? 256u : (g2 ? G2Msm::TB : G1Msm::TB); }
 uint32_t g16_msm_blocks_per_cu(bool g2) { return G16_WBITS > 10 ? (g2 ? G2Msm::GATHER_WAVES : G1Msm::GATHER_WAVES) : 1u; }

@@ -273,13 +273,18 @@ ZKP_HD inline void st_g2_jac(uint32_t* p, uint32_t idx, uint32_t row, uint32_t r
     st_fq_col(q + 4 * s, rows, g.Z.c0); st_fq_col(q + 5 * s, rows, g.Z.c1);
 }
 // C = Cp + s*A + r*B1 (Cp already contains l_aux, h and -rs*delta); proof = A || B2 || C  (snark.rs:369-373).
-// Split over lanes: thread (which, row) of step_g16_cparts computes s*A (which = 0) or r*B1 (which = 1); thread
-// (which, row) of step_g16_final serialises A (0), B2 (1) or assembles and serialises C (2).
-ZKP_HD inline void step_g16_cparts(const G16View& V, const uint32_t* sum_g1, uint32_t* tmp_g1, uint32_t which, uint32_t row) {
-    const uint32_t rows = V.rows;
-    const g1_jac P = ld_g1_jac(sum_g1, which, row, rows);                  // A or B1
+// Split over lanes: thread (part, row) of step_g16_cparts computes one GLV half of s*A (part 0, 1) or of r*B1 (part 2, 3):
+// k P = k1 P + k2 phi(P) with half-length k1, k2 (bn254_g.h), so the chain a lone wave has to walk is 132 doublings instead
+// of 256; thread (which, row) of step_g16_final serialises A (0), B2 (1) or assembles and serialises C (2).
+constexpr uint32_t G16_CPARTS = 4;
+ZKP_HD inline void step_g16_cparts(const G16View& V, const uint32_t* sum_g1, uint32_t* tmp_g1, uint32_t part, uint32_t row) {
+    const uint32_t rows = V.rows, which = part >> 1;
+    g1_jac P = ld_g1_jac(sum_g1, which, row, rows);                        // A or B1
     const fr k = ld_fr(V.rs, which == 0 ? 1 : 0, row, rows);               // s for A, r for B1 (raw canonical words)
-    st_g1_jac(tmp_g1, which, row, rows, jac_mul_raw(P, k.v));
+    glv_half h1, h2; fr_glv_split(k.v, h1, h2);
+    if (part & 1u) P.X = fq_mul(P.X, fq_glv_beta());                       // phi in Jacobian coordinates: (beta X, Y, Z)
+    const glv_half& h = (part & 1u) ? h2 : h1;
+    st_g1_jac(tmp_g1, part, row, rows, jac_mul_u128_signed(P, h.mag, h.neg));
 }
 ZKP_HD inline void step_g16_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* sum_g2, const uint32_t* tmp_g1, uint32_t which, uint32_t row) {
     const uint32_t rows = V.rows;
@@ -291,7 +296,8 @@ ZKP_HD inline void step_g16_final(const G16View& V, const uint32_t* sum_g1, cons
     } else if (which == 1) {
         uint32_t w2[32]; g2_serialize(w2, ld_g2_jac(sum_g2, 0, row, rows)); g16_put_bytes(pr + 64, w2, 32);
     } else {
-        const g1_jac Cc = jac_add(jac_add(ld_g1_jac(sum_g1, 2, row, rows), ld_g1_jac(tmp_g1, 0, row, rows)), ld_g1_jac(tmp_g1, 1, row, rows));
+        g1_jac Cc = ld_g1_jac(sum_g1, 2, row, rows);
+        for (uint32_t t = 0; t < G16_CPARTS; t++) Cc = jac_add(Cc, ld_g1_jac(tmp_g1, t, row, rows));
         uint32_t w1[16]; g1_serialize(w1, Cc); g16_put_bytes(pr + 192, w1, 16);
     }
 }

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint
 }
 
 // ---- HBM-resident tables, per-lane gathers (Groth16 key points).  The tables are sized for HBM, not for LDS: radix 2^14
-// needs 8192 entries per (key point, window) -- 640 KB for G1, 1.3 MB for G2, tens of GB per key in total -- so each lane
+// needs 8192 entries per (key point, window) -- 512 KB for G1, 1 MB for G2, tens of GB per key in total -- so each lane
 // fetches the one entry its digit selects straight from global memory (the workgroups that share a chunk sit on one XCD and
 // walk the same sub-tables at the same time, so a good part of the entries is served from that XCD's L2).  No LDS, no
 // barrier: a workgroup is four independent waves.  Loads are software-pipelined when the point type has the registers for it
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint
 // before the addition that consumes them; the digit word that selects them is fetched earlier still.
 template <class T>
 __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, uint32_t ngroups, uint32_t nblocks) {
-    constexpr uint32_t V4 = T::AFF_W / 4;
+    constexpr uint32_t V4 = T::GATHER_W / 4;          // 16-byte pieces of one packed table entry (G1: 64 bytes, G2: 128)
     const uint32_t tid = threadIdx.x;
     const uint32_t per_xcd = (nblocks + 7) / 8;
     const uint32_t linear = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);

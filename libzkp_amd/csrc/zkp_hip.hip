@@ -246,6 +246,8 @@ struct Device {
     bool ready = false;
     uint64_t generation = 0;            // bumped by zkp_hip_shutdown: staged batches of an earlier life own nothing any more
     int num_cu = 256, msm_blocks_per_cu = 3;
+    int cus_now = 0;                    // CUs the launches being enqueued may use (0 = all): set by the mixed-batch scheduler while it enqueues a variant on CU-masked streams
+    std::vector<SubBatch> subm;         // [lane]: Bulletproofs streams + workspace confined to the Bulletproofs CU partition of a mixed batch
     hipStream_t stream = nullptr;
     uint32_t* d_table = nullptr;
     // MSM chunkings: phase 1 and the inner-product rounds depend on the proofs' bit width n = 8 << w (w = 0..3); the
@@ -266,6 +268,7 @@ struct Device {
         double ms = 0; uint64_t launches = 0, adds = 0;
     };
     KProf prof[3];                      // ZKP_HIP_KERNEL_MSM_ED25519 / _BN254_G1 / _BN254_G2
+    struct Trace* trace = nullptr;      // ZKP_HIP_TRACE=<file>: a timeline of every launch of a mixed batch (tools/trace_timeline.py)
 };
 // event pair around one profiled launch (nullptrs when profiling is off)
 int prof_begin(Device::KProf& K, hipStream_t st, hipEvent_t* e1);
@@ -310,6 +313,64 @@ int prof_begin(Device::KProf& K, hipStream_t st, hipEvent_t* e1) {
 void prof_end(Device::KProf& K, hipStream_t st, hipEvent_t e1, uint64_t adds) {
     if (!e1) return;
     (void)hipEventRecord(e1, st); K.launches++; K.adds += adds;
+}
+
+// ---- launch timeline (debugging / profiling aid, off unless ZKP_HIP_TRACE names a file).  rocprofv3's kernel trace costs ~30 us of
+// host time per dispatch, which delays the later chains of a mixed batch by milliseconds and so changes the very schedule one wants to
+// see; two event records around a launch cost ~2 us.  A record holds "the stream reached this launch" and "the kernel finished".
+struct Trace {
+    struct Rec { const char* name; hipStream_t st; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool; size_t used = 0;
+    hipEvent_t origin = nullptr; bool have_origin = false;
+    std::string path;
+    hipEvent_t take() { if (used == pool.size()) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); pool.push_back(e); } return pool[used++]; }
+};
+Trace* trace_state() {
+    Device& D = dev();
+    if (D.trace) return D.trace->path.empty() ? nullptr : D.trace;
+    D.trace = new Trace();
+    const char* v = getenv("ZKP_HIP_TRACE");
+    if (v && *v) D.trace->path = v;
+    return D.trace->path.empty() ? nullptr : D.trace;
+}
+void trace_origin(hipStream_t st) {
+    Trace* T = trace_state(); if (!T) return;
+    if (!T->origin) (void)hipEventCreate(&T->origin);
+    (void)hipEventRecord(T->origin, st); T->have_origin = true;
+}
+struct TraceMark {
+    Trace* T; Trace::Rec r;
+    TraceMark(const char* name, hipStream_t st) : T(trace_state()) { if (T) { r = {name, st, T->take(), T->take()}; (void)hipEventRecord(r.a, st); } }
+    ~TraceMark() { if (T) { (void)hipEventRecord(r.b, r.st); T->recs.push_back(r); } }
+};
+#define ZKP_TRACED(name, st, ...) do { TraceMark tm_(name, st); __VA_ARGS__; } while (0)
+// appends one JSON line per batch: [[name, stream, t_reached_ms, t_done_ms], ...] relative to the batch's first enqueue
+void trace_dump() {
+    Trace* T = trace_state(); if (!T || T->recs.empty()) return;
+    (void)hipDeviceSynchronize();
+    FILE* f = fopen(T->path.c_str(), "a");
+    if (f) {
+        std::map<hipStream_t, int> ids;
+        fputs("[", f);
+        bool first = true;
+        for (auto& r : T->recs) {
+            float ta = 0, tb = 0;
+            if (!T->have_origin || hipEventElapsedTime(&ta, T->origin, r.a) != hipSuccess || hipEventElapsedTime(&tb, T->origin, r.b) != hipSuccess) continue;
+            const int id = ids.emplace(r.st, (int)ids.size()).first->second;
+            fprintf(f, "%s[\"%s\", %d, %.4f, %.4f]", first ? "" : ", ", r.name, id, ta, tb); first = false;
+        }
+        fputs("]\n", f);
+        fclose(f);
+    }
+    (void)hipGetLastError();
+    T->recs.clear(); T->used = 0; T->have_origin = false;
+}
+void trace_release() {
+    Trace* T = dev().trace; if (!T) return;
+    for (auto e : T->pool) (void)hipEventDestroy(e);
+    if (T->origin) (void)hipEventDestroy(T->origin);
+    delete T; dev().trace = nullptr;
 }
 
 int upload_layout(DevLayout& D, const MsmLayout& L) {
@@ -368,7 +429,7 @@ const DevLayout& pick_layout(const LayoutSet& S, uint32_t rows) {
     // workgroups (measured: 1.5 rounds cost 1.30x of 1 round, 2 rounds 1.00x with half-size chunks).  Take the window-
     // granular layout that minimises rounds x (windows per workgroup + per-workgroup overhead) + the partial-sum work
     // that grows with the chunk count; g_fill scales the resident count (benchmarking knob, default 1).
-    const double resident = g_fill * (double)dev().num_cu * dev().msm_blocks_per_cu;
+    const double resident = g_fill * (double)(dev().cus_now ? dev().cus_now : dev().num_cu) * dev().msm_blocks_per_cu;
     const uint32_t groups = (rows + EdMsm::TB - 1) / EdMsm::TB;
     size_t best = MAXT; double best_cost = 1e300;
     for (size_t i = MAXT; i < S.cand.size(); i++) {
@@ -441,16 +502,38 @@ int init_device() {
     if ((rc = ensure_family(6))) return rc;
     uint32_t ns = g_subbatches; if (ns < 1) ns = 1; if (ns > 8) ns = 8;
     D.nsub = ns;
-    D.sub.resize((size_t)NSLOTS * ns);
-    for (auto& sb : D.sub) {
+    D.sub.resize((size_t)NSLOTS * ns);       // streams and events of a slot exist from its first use (ensure_sub)
+    D.ready = true;
+    return 0;
+}
+// ---- CU partition of a mixed batch (experiment, OFF by default: ZKP_HIP_BP_CUS = CUs per XCD for the Bulletproofs streams).  The
+// Bulletproofs prover is a chain of ~50 dependent launches whose MSM workgroups need whole CUs (1024 lanes, 120 KB of LDS) and whose
+// lane = proof kernels need 120-256 VGPRs; next to the Groth16 gather kernels (three 136-VGPR waves per SIMD, workgroups that live
+// 1.5-2.5 ms) each of those launches waits for workgroup slots (launch trace, round 3: first inner-product round reached at ~10 ms of a
+// 14 ms step, the last rounds then run on an idle GPU).  Giving each side its own CUs (hipExtStreamCreateWithCUMask; mask bit b = CU
+// b / 8 of XCD b mod 8, tools/cumask_probe.hip; every grid sized for its partition) removes the waiting but not the arithmetic: the
+// Bulletproofs MSMs are 2.2 ms of whole-GPU work, so on a quarter of the CUs the chain takes 12+ ms and the step 16.3-16.8 ms (8 or 12
+// CUs per XCD) against 13.7 ms unpartitioned on the same box; 6 and 10 CUs per XCD measured 21-27 ms.  Kept as a knob.
+int bp_cus_per_xcd() { static const int v = env_int("ZKP_HIP_BP_CUS", 0); return v < 0 ? 0 : v > 24 ? 24 : v; }
+int make_masked_stream(hipStream_t* out, bool bp_part) {
+    const int per_xcd = dev().num_cu / 8, nb = bp_cus_per_xcd();
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < per_xcd * 8 && b < 256; b++) if ((b < nb * 8) == bp_part) mask[b >> 5] |= 1u << (b & 31);
+    HIP_TRY(hipExtStreamCreateWithCUMask(out, 8, mask));
+    return 0;
+}
+int partition_cus(bool bp_part) { const int nb = bp_cus_per_xcd() * 8; return bp_part ? nb : dev().num_cu - nb; }
+int ensure_sub(SubBatch& sb, bool masked = false) {
+    if (sb.stream) return 0;
+    if (masked) { int rc; if ((rc = make_masked_stream(&sb.stream, true)) || (rc = make_masked_stream(&sb.side, true))) return rc; }
+    else {
         HIP_TRY(hipStreamCreateWithPriority(&sb.stream, hipStreamNonBlocking, stream_priority(bp_priority_level())));
         HIP_TRY(hipStreamCreateWithPriority(&sb.side, hipStreamNonBlocking, stream_priority(bp_priority_level())));
-        HIP_TRY(hipEventCreateWithFlags(&sb.start, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&sb.done, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&sb.side_go, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&sb.side_done, hipEventDisableTiming));
     }
-    D.ready = true;
+    HIP_TRY(hipEventCreateWithFlags(&sb.start, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sb.done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sb.side_go, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sb.side_done, hipEventDisableTiming));
     return 0;
 }
 
@@ -554,15 +637,15 @@ int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32
     hipEvent_t e1 = nullptr;
     int rc = prof_begin(dev().prof[0], st, &e1);
     if (rc) return rc;
-    k_msm_dma<EdMsm><<<grid, EdMsm::TB, msm_lds_bytes<EdMsm>(), st>>>(m, ngroups, nblocks);
+    ZKP_TRACED("k_msm_dma<EdMsm>", st, k_msm_dma<EdMsm><<<grid, EdMsm::TB, msm_lds_bytes<EdMsm>(), st>>>(m, ngroups, nblocks));
     prof_end(dev().prof[0], st, e1, D.adds_per_row * rows);
     return 0;
 }
 int launch_reduce(const DevLayout& D, uint32_t rows, const uint32_t* partial, uint32_t* sums, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
     ReduceView R; R.rows = rows; R.ntargets = D.ntargets; R.partial = partial; R.target_chunk_begin = D.target_chunk_begin;
     R.enc = enc; R.out_off = out_off; R.out = out; R.corr = nullptr;
-    k_sum_t<EdMsm><<<dim3((rows + 63) / 64, D.ntargets), SUM_TB, 0, st>>>(R, sums);
-    k_encode<<<dim3((rows + TW - 1) / TW, D.ntargets), TW, 0, st>>>(R, sums);
+    ZKP_TRACED("k_sum_t<EdMsm>", st, k_sum_t<EdMsm><<<dim3((rows + 63) / 64, D.ntargets), SUM_TB, 0, st>>>(R, sums));
+    ZKP_TRACED("k_encode", st, k_encode<<<dim3((rows + TW - 1) / TW, D.ntargets), TW, 0, st>>>(R, sums));
     return 0;
 }
 int msm_and_encode(const LayoutSet& S, uint32_t rows, const uint32_t* digits, uint32_t* partial, uint32_t* sums, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
@@ -584,24 +667,24 @@ int run_pipeline(const Ws& w, uint32_t M, uint32_t C, hipStream_t st, SubBatch& 
     if (C) {
         hipStream_t cs = forked ? lane.side : st;
         if (forked) { HIP_TRY(hipEventRecord(lane.side_go, st)); HIP_TRY(hipStreamWaitEvent(cs, lane.side_go, 0)); }
-        k_ctask<<<(C + TB - 1) / TB, TB, 0, cs>>>(w.T);
+        ZKP_TRACED("k_ctask", cs, k_ctask<<<(C + TB - 1) / TB, TB, 0, cs>>>(w.T));
         if ((rc = msm_and_encode(dev().ct, C, w.T.digits, w.ct_partial, w.ct_sums, w.ct_enc, w.ct_off, w.V.out, cs))) return rc;
         if (forked) HIP_TRY(hipEventRecord(lane.side_done, cs));
     }
     if (M == 0) { HIP_TRY(hipGetLastError()); return 0; }
-    k_tape<<<dim3(gj.x, tape_slots(n) + 1), TB, 0, st>>>(w.V);
+    ZKP_TRACED("k_tape", st, k_tape<<<dim3(gj.x, tape_slots(n) + 1), TB, 0, st>>>(w.V));
     if ((rc = msm_and_encode(F.p1, M, w.V.d1, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
-    k_transcript1<<<gw, TW, 0, st>>>(w.V);
-    k_poly<<<dim3(gj.x, n), TB, 0, st>>>(w.V);
-    k_poly_sum<<<(M + 7) / 8, TW, 0, st>>>(w.V);
+    ZKP_TRACED("k_transcript1", st, k_transcript1<<<gw, TW, 0, st>>>(w.V));
+    ZKP_TRACED("k_poly", st, k_poly<<<dim3(gj.x, n), TB, 0, st>>>(w.V));
+    ZKP_TRACED("k_poly_sum", st, k_poly_sum<<<(M + 7) / 8, TW, 0, st>>>(w.V));
     if ((rc = msm_and_encode(dev().p2, M, w.V.d2, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
-    k_transcript2<<<gw, TW, 0, st>>>(w.V);
-    k_lr_init<<<dim3(gj.x, n), TB, 0, st>>>(w.V);
+    ZKP_TRACED("k_transcript2", st, k_transcript2<<<gw, TW, 0, st>>>(w.V));
+    ZKP_TRACED("k_lr_init", st, k_lr_init<<<dim3(gj.x, n), TB, 0, st>>>(w.V));
     for (uint32_t r = 0; r < lg; r++) {
-        k_round_prep<<<dim3(gj.x, n), TB, 0, st>>>(w.V, r);
-        k_round_sum<<<gw, TW, 0, st>>>(w.V, r);
+        ZKP_TRACED("k_round_prep", st, k_round_prep<<<dim3(gj.x, n), TB, 0, st>>>(w.V, r));
+        ZKP_TRACED("k_round_sum", st, k_round_sum<<<gw, TW, 0, st>>>(w.V, r));
         if ((rc = msm_and_encode(F.rd[r], M, w.V.dr, w.partial, w.sums, w.V.enc, nullptr, nullptr, st))) return rc;
-        k_transcript_round<<<gw, TW, 0, st>>>(w.V, r);
+        ZKP_TRACED("k_transcript_round", st, k_transcript_round<<<gw, TW, 0, st>>>(w.V, r));
     }
     if (forked) HIP_TRY(hipStreamWaitEvent(st, lane.side_done, 0));
     HIP_TRY(hipGetLastError());
@@ -618,7 +701,7 @@ __global__ void k_any_failed(const int32_t* status, uint32_t n, int* flag) {
 // MSM keeps the CUs busy.  `st` (the caller's stream) is forked into the sub-streams and joined again.
 int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_t* d_min, const uint64_t* d_max, uint32_t lg,
                               const uint8_t* d_seeds, uint8_t* d_out, uint64_t stride, uint32_t* d_out_len, int32_t* d_status,
-                              hipStream_t st, int* any_failed) {
+                              hipStream_t st, int* any_failed, int slot_hint = -1, bool masked = false) {
     if (n == 0) { if (any_failed) *any_failed = 0; return 0; }
     if (n > (1u << 30)) return fail(ZKP_HIP_E_ARGUMENT, "batch too large");
     if (stride < range_envelope_bytes(lg)) return fail(ZKP_HIP_E_ARGUMENT, "stride is smaller than the proof (1478 bytes for n_bits = 64)");
@@ -627,13 +710,26 @@ int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_
     uint32_t nsub = dev().nsub;
     if (n < 512) nsub = 1;                       // small batches: one stream
     const uint64_t per = (n + nsub - 1) / nsub;
-    const uint32_t slot = dev().next_slot; dev().next_slot = (dev().next_slot + 1) % NSLOTS;
-    SubBatch& first = dev().sub[(size_t)slot * dev().nsub];
+    // slot (streams + workspace): the scheduler's lane when it calls; otherwise slot 0 unless a batch is still running there (a
+    // caller that keeps two batches in flight from two of its own streams then gets both slots)
+    uint32_t slot = 0;
+    if (slot_hint >= 0) slot = (uint32_t)slot_hint % NSLOTS;
+    else {
+        SubBatch& s0 = dev().sub[0];
+        if (s0.used && hipEventQuery(s0.done) == hipErrorNotReady) { slot = 1 + dev().next_slot % (NSLOTS - 1); dev().next_slot++; }
+        (void)hipGetLastError();
+    }
+    if (masked) {                                  // the scheduler's CU partition: one slice on the lane's masked streams
+        nsub = 1;
+        if (dev().subm.size() < NSLOTS) dev().subm.resize(NSLOTS);
+        if ((rc = ensure_sub(dev().subm[slot], true))) return rc;
+    } else for (uint32_t h = 0; h < dev().nsub; h++) if ((rc = ensure_sub(dev().sub[(size_t)slot * dev().nsub + h]))) return rc;
+    SubBatch& first = masked ? dev().subm[slot] : dev().sub[(size_t)slot * dev().nsub];
     HIP_TRY(hipEventRecord(first.start, st));
     for (uint32_t h = 0; h < nsub; h++) {
         const uint64_t lo = h * per, hi = (lo + per < n) ? lo + per : n;
         if (lo >= hi) continue;
-        SubBatch& sb = dev().sub[(size_t)slot * dev().nsub + h];
+        SubBatch& sb = masked ? dev().subm[slot] : dev().sub[(size_t)slot * dev().nsub + h];
         const uint32_t C = (uint32_t)(hi - lo), M = 2 * C;
         if ((rc = ensure_workspace(sb, M, C))) return rc;
         Ws w; carve((uint8_t*)sb.ws, M, C, dev().max_chunks, &w);
@@ -642,7 +738,7 @@ int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_
         w.V.out = d_out + lo * stride;
         HIP_TRY(hipStreamWaitEvent(sb.stream, first.start, 0));        // (the slot's previous batch is ahead of this one on sb.stream)
         if (sb.used) HIP_TRY(hipStreamWaitEvent(sb.stream, sb.done, 0));   // ... unless it was a host-described job list on another stream (run_jobs_on)
-        k_build_range<<<(C + TB - 1) / TB, TB, 0, sb.stream>>>(w.J, C, d_value + lo, d_min + lo, d_max + lo, lg, w.V.out, stride, d_out_len + lo, d_status + lo);
+        ZKP_TRACED("k_build_range", sb.stream, k_build_range<<<(C + TB - 1) / TB, TB, 0, sb.stream>>>(w.J, C, d_value + lo, d_min + lo, d_max + lo, lg, w.V.out, stride, d_out_len + lo, d_status + lo));
         if ((rc = run_pipeline(w, M, C, sb.stream, sb))) return rc;
         HIP_TRY(hipEventRecord(sb.done, sb.stream)); sb.used = true;
         HIP_TRY(hipStreamWaitEvent(st, sb.done, 0));
@@ -679,7 +775,7 @@ int run_jobs_on(SubBatch& sb, const HostJobs& H, const uint8_t* d_seeds, uint8_t
     const uint32_t M = (uint32_t)H.v.size(), C = (uint32_t)H.ct_v.size();
     if (M == 0 && C == 0) return 0;
     int rc;
-    if ((rc = ensure_family(lg))) return rc;
+    if ((rc = ensure_family(lg)) || (rc = ensure_sub(sb))) return rc;
     if (sb.used) HIP_TRY(hipStreamWaitEvent(st, sb.done, 0));          // an asynchronous device-pointer call may still own this workspace
     if ((rc = ensure_workspace(sb, M ? M : 1, C ? C : 1))) return rc;
     Ws w; carve((uint8_t*)sb.ws, M ? M : 1, C ? C : 1, dev().max_chunks, &w);
@@ -870,14 +966,20 @@ void zkp_hip_shutdown(void) {
         bpv_release_all();
         stark_release_all();
         d->pool.release_all();
-        for (auto& sb : d->sub) {
-            (void)hipFree(sb.ws); (void)hipStreamDestroy(sb.stream); (void)hipStreamDestroy(sb.side);
-            (void)hipEventDestroy(sb.start); (void)hipEventDestroy(sb.done); (void)hipEventDestroy(sb.side_go); (void)hipEventDestroy(sb.side_done);
+        for (auto* vec : {&d->sub, &d->subm}) {
+            for (auto& sb : *vec) {
+                if (sb.ws) (void)hipFree(sb.ws);
+                if (!sb.stream) continue;
+                (void)hipStreamDestroy(sb.stream); (void)hipStreamDestroy(sb.side);
+                (void)hipEventDestroy(sb.start); (void)hipEventDestroy(sb.done); (void)hipEventDestroy(sb.side_go); (void)hipEventDestroy(sb.side_done);
+            }
+            vec->clear();
         }
-        d->sub.clear();
+        d->cus_now = 0;
         (void)hipFree(d->d_table); d->d_table = nullptr;
         free_set(d->p2); free_set(d->ct);
         for (auto& F : d->fam) { free_set(F.p1); for (auto& s : F.rd) free_set(s); F.ready = false; }
+        trace_release();
         for (auto& K : d->prof) { for (auto& e : K.ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); } K = Device::KProf(); }
         (void)hipStreamDestroy(d->stream); d->stream = nullptr;
         d->ready = false; d->profiling = false; d->max_chunks = 0; d->next_slot = 0; d->generation++;

@@ -62,7 +62,8 @@ void emul_g1_xyzz9_chain(const uint32_t o[16], const uint32_t* pts, const int* s
     uint32_t mx = 0;
     for (int i = 0; i < n; i++) {
         const g1_aff a = load_g1(pts + 16 * i);
-        g1_aff9 q{fq9_from_fq(a.x), fq9_from_fq(a.y)};
+        uint32_t e[16]; fq9_pack8(e, fq9_from_fq(a.x)); fq9_pack8(e + 8, fq9_from_fq(a.y));      // the 64-byte table entry
+        g1_aff9 q{fq9_unpack8(e), fq9_unpack8(e + 8)};
         q.y = fq9_select(signs[i] < 0, fq9_neg_k<4>(q.y), q.y);
         acc = g1_mmadd9(acc, q);
         for (int k = 0; k < 9; k++) { const uint32_t w[4] = {acc.X.v[k], acc.Y.v[k], acc.ZZ.v[k], acc.ZZZ.v[k]}; for (uint32_t x : w) if (x > mx) mx = x; }
@@ -74,6 +75,18 @@ void emul_g1_xyzz9_chain(const uint32_t o[16], const uint32_t* pts, const int* s
 void emul_fq9_mul(const uint32_t a[8], const uint32_t b[8], uint32_t out[8]) {
     const fq9 x = fq9_from_fq(fq_from_raw(a)), y = fq9_from_fq(fq_from_raw(b));
     fq_to_raw(out, fq9_to_fq(fq9_mul(x, y)));
+}
+// the key-table form of a coordinate: eight words in, the nine limbs the loop sees out, and those limbs packed again
+void emul_fq9_pack(const uint32_t w[8], uint32_t limbs[9], uint32_t again[8]) {
+    const fq9 v = fq9_unpack8(w);
+    for (int i = 0; i < 9; i++) limbs[i] = v.v[i];
+    fq9_pack8(again, v);
+}
+// what k_g16_build_table stores for the coordinate a (raw canonical in): pack8(fq9_from_fq(to Montgomery form)), and the nine limbs before packing
+void emul_fq9_entry(const uint32_t a[8], uint32_t packed[8], uint32_t limbs[9]) {
+    const fq9 v = fq9_from_fq(fq_from_raw(a));
+    for (int i = 0; i < 9; i++) limbs[i] = v.v[i];
+    fq9_pack8(packed, v);
 }
 void emul_fq9_ops(const uint32_t a[8], const uint32_t b[8], uint32_t sq[8], uint32_t fused[8], uint32_t sub[8]) {
     const fq9 x = fq9_from_fq(fq_from_raw(a)), y = fq9_from_fq(fq_from_raw(b));
@@ -96,7 +109,9 @@ void emul_g2_xyzz9_chain(const uint32_t o[32], const uint32_t* pts, const int* s
     uint32_t mx = 0;
     for (int i = 0; i < n; i++) {
         const g2_aff a = load_g2(pts + 32 * i);
-        const g2_aff9 q{fq2_9_from_fq2(a.x), fq2_9_from_fq2(a.y)};
+        uint32_t e[32];                                                             // the 128-byte table entry
+        fq9_pack8(e, fq9_from_fq(a.x.c0)); fq9_pack8(e + 8, fq9_from_fq(a.x.c1)); fq9_pack8(e + 16, fq9_from_fq(a.y.c0)); fq9_pack8(e + 24, fq9_from_fq(a.y.c1));
+        const g2_aff9 q{fq2_9{fq9_unpack8(e), fq9_unpack8(e + 8)}, fq2_9{fq9_unpack8(e + 16), fq9_unpack8(e + 24)}};
         acc = g2_mmadd9(acc, q, signs[i] < 0);
         const fq9* c = reinterpret_cast<const fq9*>(&acc);
         for (int t = 0; t < 8; t++) for (int k = 0; k < 9; k++) if (c[t].v[k] > mx) mx = c[t].v[k];
@@ -123,6 +138,16 @@ void emul_fr_from_wide(const uint32_t w[16], uint32_t out[8]) { fp_to_raw(out, f
 void emul_g1_lincomb(const uint32_t p[16], const uint32_t q[16], const uint32_t k1[8], const uint32_t k2[8], uint32_t out[16]) {
     g1_jac a = jac_mul_raw(jac_from_aff(load_g1(p)), k1), b = jac_mul_raw(jac_from_aff(load_g1(q)), k2);
     g1_serialize(out, jac_add(a, b));
+}
+// k * P through the GLV split of the Groth16 C element (bn254_g.h): halves (magnitude words + sign) out, and serialize(k1 P' + k2 phi(P'))
+// for P' = 2 P brought in with Z != 1; must equal serialize(2 k P)
+void emul_g1_glv_mul(const uint32_t p[16], const uint32_t k[8], uint32_t halves[10], uint32_t out[16]) {
+    glv_half h1, h2; fr_glv_split(k, h1, h2);
+    for (int i = 0; i < 4; i++) { halves[i] = h1.mag[i]; halves[5 + i] = h2.mag[i]; }
+    halves[4] = h1.neg; halves[9] = h2.neg;
+    g1_jac P = jac_dbl(jac_from_aff(load_g1(p))), Q = P;
+    Q.X = fq_mul(Q.X, fq_glv_beta());
+    g1_serialize(out, jac_add(jac_mul_u128_signed(P, h1.mag, h1.neg), jac_mul_u128_signed(Q, h2.mag, h2.neg)));
 }
 void emul_g2_lincomb(const uint32_t p[32], const uint32_t q[32], const uint32_t k1[8], const uint32_t k2[8], uint32_t out[32]) {
     g2_jac a = jac_mul_raw(jac_from_aff(load_g2(p)), k1), b = jac_mul_raw(jac_from_aff(load_g2(q)), k2);

@@ -132,6 +132,51 @@ def test_msm_inner_loop_lazy(libs):
     assert I(o32).to_bytes(128, "little") == b.ser_g2(b.G2C.mul_pt(b.G2, total)) and mx.value < 1 << 29
 
 
+def test_glv_split_of_the_c_element_multiplications(libs):
+    """fr_glv_split / jac_mul_u128_signed (bn254_g.h): k = k1 + k2 lambda mod r with |k1|, |k2| < 2^128 for every k < 2^256 the
+    floor quotients can meet, and k1 P + k2 phi(P) = k P."""
+    lib, _ = libs
+    rnd = random.Random(31)
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    assert (lam * lam + lam + 1) % b.R == 0
+    g1w = lambda pt: [(pt[0] >> (32 * i)) & 0xFFFFFFFF for i in range(8)] + [(pt[1] >> (32 * i)) & 0xFFFFFFFF for i in range(8)]  # noqa: E731
+    P = b.G1C.mul_pt(b.G1, rnd.randrange(1, b.R))
+    pw = (ctypes.c_uint32 * 16)(*g1w(P))
+    ks = [0, 1, 2, b.R - 1, b.R - 2, lam, lam + 1, b.R - lam, (1 << 254) - 1, (1 << 128) - 1, 1 << 128, 1 << 127] + [rnd.randrange(b.R) for _ in range(40)] + [rnd.randrange(1 << 64) for _ in range(4)]
+    for k in ks:
+        halves, out = (ctypes.c_uint32 * 10)(), (ctypes.c_uint32 * 16)()
+        lib.emul_g1_glv_mul(pw, W(k), halves, out)
+        k1 = sum(int(halves[i]) << (32 * i) for i in range(4)) * (-1 if halves[4] else 1)
+        k2 = sum(int(halves[5 + i]) << (32 * i) for i in range(4)) * (-1 if halves[9] else 1)
+        assert (k1 + k2 * lam) % b.R == k % b.R
+        want = b.G1C.mul_pt(P, 2 * k % b.R)
+        assert I(out).to_bytes(64, "little") == b.ser_g1(want), k
+
+
+def test_key_table_entries_pack_into_eight_words(libs):
+    """fq9_pack8 / fq9_unpack8 (bn254_fq9.h): a G1 table entry is 64 bytes, a G2 entry 128.  The eight words are the nine-limb
+    integer re-sliced; whatever k_g16_build_table stores (2 x R10 mod-p representatives, < 2.4 p) lies below 2^256 and survives."""
+    lib, _ = libs
+    rnd = random.Random(29)
+    p = b.P
+    W8 = ctypes.c_uint32 * 8
+    for trial in range(300):
+        n = rnd.choice((0, 1, (1 << 256) - 1, rnd.randrange(1 << 256), rnd.randrange(1 << 29), (1 << 232) | rnd.randrange(1 << 232)))
+        w = W8(*[(n >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+        limbs, again = (ctypes.c_uint32 * 9)(), W8()
+        lib.emul_fq9_pack(w, limbs, again)
+        assert all(limbs[i] < 1 << 29 for i in range(8)) and limbs[8] < 1 << 24
+        assert sum(int(limbs[i]) << (29 * i) for i in range(9)) == n and list(again) == list(w)
+    R9 = 1 << 261
+    for trial in range(300):
+        a = rnd.choice((0, 1, p - 1, rnd.randrange(p)))
+        packed, limbs = W8(), (ctypes.c_uint32 * 9)()
+        lib.emul_fq9_entry(W8(*[(a >> (32 * i)) & 0xFFFFFFFF for i in range(8)]), packed, limbs)
+        v = sum(int(limbs[i]) << (29 * i) for i in range(9))
+        assert v < 3 * p and v < 1 << 256 and v % p == a * R9 % p          # the loop's Montgomery form, inside the packable range
+        assert I(packed) == v
+
+
 def _run(lib, kind, value, the_set, seed):
     nv, m = (334, 512) if kind == 0 else (653, 1024)
     z = np.zeros((nv, 8), dtype=np.uint32)
