@@ -78,7 +78,7 @@ struct DevSync { __device__ __forceinline__ void operator()() const { __syncthre
 // 512 lanes: the 108 KB LDS image of a membership proof allows one workgroup per CU, so the workgroup itself has to bring the
 // waves (2 per SIMD) that hide the LDS latency of the butterfly stages
 static constexpr int QAP_TB = 512;
-__global__ void __launch_bounds__(QAP_TB) k_g16_qap(G16View V, G16Circuit C) {
+__global__ void __launch_bounds__(QAP_TB, ZKP_LAT_WAVES) k_g16_qap(G16View V, G16Circuit C) {
     extern __shared__ uint32_t g16_lds[];
     G16Lds L; L.base = g16_lds; L.m = C.m;
     g16_qap_proof(V, C, L, blockIdx.x, threadIdx.x, QAP_TB, DevSync());
@@ -159,9 +159,9 @@ template __global__ void k_msm_dma<G1Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_msm_dma<G2Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_msm_gather<G1Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_msm_gather<G2Msm>(MsmView, uint32_t, uint32_t);
-static constexpr uint32_t G16_SUM_ROWS = 16;         // 32 slices per row (msm_kernel.h)
-template __global__ void k_sum_t<G1Msm, G16_SUM_ROWS>(ReduceView, uint32_t*);
-template __global__ void k_sum_t<G2Msm, G16_SUM_ROWS>(ReduceView, uint32_t*);
+static constexpr uint32_t G16_SUM_ROWS = 8, G16_SUM_TB = 256;         // 32 slices per row (msm_kernel.h)
+template __global__ void k_sum_t<G1Msm, G16_SUM_ROWS, G16_SUM_TB>(ReduceView, uint32_t*);
+template __global__ void k_sum_t<G2Msm, G16_SUM_ROWS, G16_SUM_TB>(ReduceView, uint32_t*);
 template __global__ void k_g16_build_table<fq, 20>(const uint32_t*, uint32_t, uint32_t*, uint32_t);
 template __global__ void k_g16_build_table<fq2, 40>(const uint32_t*, uint32_t, uint32_t*, uint32_t);
 
@@ -214,7 +214,7 @@ void g16_launch_msm(bool g2, const MsmView& m, hipStream_t st) {
 }
 void g16_launch_sum(bool g2, const ReduceView& R, uint32_t* sums, hipStream_t st) {
     const dim3 grid((R.rows + G16_SUM_ROWS - 1) / G16_SUM_ROWS, R.ntargets);
-    if (!g2) k_sum_t<G1Msm, G16_SUM_ROWS><<<grid, SUM_TB, 0, st>>>(R, sums);
-    else k_sum_t<G2Msm, G16_SUM_ROWS><<<grid, SUM_TB, 0, st>>>(R, sums);
+    if (!g2) k_sum_t<G1Msm, G16_SUM_ROWS, G16_SUM_TB><<<grid, G16_SUM_TB, 0, st>>>(R, sums);
+    else k_sum_t<G2Msm, G16_SUM_ROWS, G16_SUM_TB><<<grid, G16_SUM_TB, 0, st>>>(R, sums);
 }
 void g16_launch_serialize(bool g2, const uint32_t* jac, uint32_t rows, uint8_t* out, hipStream_t st) { k_g16_serialize<<<(rows + TW - 1) / TW, TW, 0, st>>>(g2, jac, rows, out); }

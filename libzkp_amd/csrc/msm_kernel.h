@@ -152,17 +152,17 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
 // loads -- entry of step i+1, digit word of step i+2, descriptor of step i+3 -- and never waits behind one.  Kernel times were
 // within 1 % of this loop (G1 4.01 vs 4.05 ms, G2 1.70 vs 1.67 ms at 1024 membership rows): the metadata loads at the head of an
 // iteration are not what separates this kernel from the bare addition loop of tools/g1_add_rate.hip)
-// Partial sums of one target.  A block owns ROWS consecutive rows and cuts the target's chunk partials into SUM_TB / ROWS slices
-// per row: every lane adds its slice's partials (every (SUM_TB / ROWS)-th chunk), then a tree through LDS joins the slices.
-// ROWS = 64 (8 slices: lane = row within a wave, every load a full 256-byte segment) for the ed25519 sums, whose additions are
-// cheap; ROWS = 16 (32 slices) for the BN254 sums, which are chains of 15-20 Jacobian additions of ~30-60 us each on a handful of
-// waves -- latency on the Groth16 prover's critical path: 32 slices make it 8 additions deep (k_sum_t<G2Msm, 16>).
-static constexpr int SUM_TB = 512;
-template <class T, uint32_t ROWS = 64>
-__global__ void __launch_bounds__(SUM_TB) k_sum_t(ReduceView R, uint32_t* sums) {
-    constexpr uint32_t SLICES = SUM_TB / ROWS;
-    static_assert(SUM_TB % ROWS == 0 && (SLICES & (SLICES - 1)) == 0, "slices per row: a power of two");
-    __shared__ uint32_t lds[T::ACC_W * (SUM_TB / 2)];              // [word][SLICES / 2 x ROWS]
+// Partial sums of one target.  A block of NTHREADS lanes owns ROWS consecutive rows and cuts the target's chunk partials into
+// NTHREADS / ROWS slices per row: every lane adds its slice's partials (every (NTHREADS / ROWS)-th chunk), then a tree through LDS
+// joins the slices.  The ed25519 sums (cheap additions) take 8 slices of 32 rows; the BN254 sums are chains of 15-20 Jacobian additions
+// of ~30-60 us each on a handful of waves -- latency on the Groth16 prover's critical path -- and take 32 slices (8 additions deep).
+// Blocks are 256 lanes: one wave per SIMD, so that in a mixed batch a block finds room beside the gather kernels' waves (a 512-lane
+// block needed two free wave slots' worth of registers on all four SIMDs of a CU at once and waited milliseconds for them).
+template <class T, uint32_t ROWS, uint32_t NTHREADS, uint32_t MIN_WAVES = 1>
+__global__ void __launch_bounds__(NTHREADS, MIN_WAVES) k_sum_t(ReduceView R, uint32_t* sums) {
+    constexpr uint32_t SLICES = NTHREADS / ROWS;
+    static_assert(NTHREADS % ROWS == 0 && (SLICES & (SLICES - 1)) == 0, "slices per row: a power of two");
+    __shared__ uint32_t lds[T::ACC_W * (NTHREADS / 2)];              // [word][SLICES / 2 x ROWS]
     const uint32_t rl = threadIdx.x % ROWS, slice = threadIdx.x / ROWS;
     const uint32_t row = blockIdx.x * ROWS + rl, target = blockIdx.y;
     const bool active = row < R.rows;
@@ -177,9 +177,9 @@ __global__ void __launch_bounds__(SUM_TB) k_sum_t(ReduceView R, uint32_t* sums) 
         }
     }
     for (uint32_t stride = SLICES / 2; stride >= 1; stride >>= 1) {
-        if (slice >= stride && slice < 2 * stride) T::store(lds, 0, (slice - stride) * ROWS + rl, SUM_TB / 2, acc);
+        if (slice >= stride && slice < 2 * stride) T::store(lds, 0, (slice - stride) * ROWS + rl, NTHREADS / 2, acc);
         __syncthreads();
-        if (slice < stride) acc = T::add(acc, T::load(lds, 0, slice * ROWS + rl, SUM_TB / 2));
+        if (slice < stride) acc = T::add(acc, T::load(lds, 0, slice * ROWS + rl, NTHREADS / 2));
         __syncthreads();
     }
     if (slice == 0 && active) {

@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(TB) k_tape(BpView V) {
     const uint32_t job = blockIdx.x * TB + threadIdx.x;
     if (job < V.M) step_tape(V, blockIdx.y, job);
 }
-__global__ void __launch_bounds__(TB) k_poly(BpView V) {
+__global__ void __launch_bounds__(TB, ZKP_LAT_WAVES) k_poly(BpView V) {
     const uint32_t job = blockIdx.x * TB + threadIdx.x;
     if (job < V.M) step_poly(V, blockIdx.y, job);
 }
@@ -66,7 +66,7 @@ __device__ __forceinline__ ScTriple triple_tree8(ScTriple t, uint32_t* lds) {
     }
     return t;
 }
-__global__ void __launch_bounds__(TW) k_poly_sum(BpView V) {
+__global__ void __launch_bounds__(TW, ZKP_LAT_WAVES) k_poly_sum(BpView V) {
     __shared__ uint32_t lds[24 * TW];
     const uint32_t job = blockIdx.x * 8 + (threadIdx.x & 7u), part = threadIdx.x >> 3;
     const bool active = job < V.M;
@@ -79,11 +79,11 @@ __global__ void __launch_bounds__(TB) k_lr_init(BpView V) {
     const uint32_t job = blockIdx.x * TB + threadIdx.x;
     if (job < V.M) step_lr_init(V, blockIdx.y, job);
 }
-__global__ void __launch_bounds__(TB) k_round_prep(BpView V, uint32_t r) {
+__global__ void __launch_bounds__(TB, ZKP_LAT_WAVES) k_round_prep(BpView V, uint32_t r) {
     const uint32_t job = blockIdx.x * TB + threadIdx.x;
     if (job < V.M) step_round_prep(V, r, blockIdx.y, job);
 }
-__global__ void __launch_bounds__(TW) k_round_sum(BpView V, uint32_t r) {      // <= 64 additions per lane: the 8-lane split measured slower here
+__global__ void __launch_bounds__(TW, ZKP_LAT_WAVES) k_round_sum(BpView V, uint32_t r) {      // <= 64 additions per lane: the 8-lane split measured slower here
     const uint32_t job = blockIdx.x * TW + threadIdx.x;
     if (job < V.M) step_round_sum(V, r, job);
 }
@@ -141,7 +141,8 @@ struct EdMsm {      // edwards25519 affine-Niels tables, extended-coordinate acc
 };
 
 template __global__ void k_msm_dma<EdMsm>(MsmView, uint32_t, uint32_t);
-template __global__ void k_sum_t<EdMsm>(ReduceView, uint32_t*);
+static constexpr uint32_t ED_SUM_ROWS = 32, ED_SUM_TB = 256;      // 8 slices per row; one wave per SIMD
+template __global__ void k_sum_t<EdMsm, ED_SUM_ROWS, ED_SUM_TB>(ReduceView, uint32_t*);
 
 // ================================================================================================ host
 namespace {
@@ -292,14 +293,20 @@ uint32_t g_budget_request = 0;     // 0 = choose per launch
 double g_fill = 1.0;               // benchmarking knob: scales the resident-workgroup count the Bulletproofs MSM chunking aims at
 uint32_t g_subbatches = 1;         // >1: independent slices on separate streams (measured slower on MI355X: see DESIGN.md)
 // Stream priorities (mixed batches run their variants on separate streams).  0 = greatest priority of the device, 1 = default,
-// 2 = least.  The Bulletproofs pipeline is a chain of ~80 dependent launches, most of them short: it gets the greatest priority
-// so that each of its kernels starts as soon as workgroup slots free up, while the long Groth16 MSM grids take the least.
+// 2 = least.  What counts is the order: the Bulletproofs pipeline -- a chain of ~50 dependent launches, most of them short -- above
+// the Groth16 streams with their long MSM grids (4096-op mixed batch, same box: 13.8-13.9 ms with Bulletproofs above Groth16, 16.0 ms
+// with everything at one level).  Bulletproofs and the STARK sit at the DEFAULT level and Groth16 at the least: with the Bulletproofs
+// streams at the greatest level (rounds 1-2) a range-only batch entered through the host-buffer API, whose copies and fork / join run
+// on a default-level stream, lost ~50 us between consecutive kernels once a mixed batch had created the other levels' queues
+// (5.9-6.2 against 4.2 ms per 1024 ops; launch traces in round 3) -- the "C2 regression" of round 2's bench line was that, hit on
+// every second call because the calls alternated between two stream sets.
 int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
 int stream_priority(int level) {
     int least = 0, greatest = 0; (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     return level == 0 ? greatest : level == 2 ? least : (least + greatest) / 2;
 }
-int bp_priority_level() { static const int v = env_int("ZKP_HIP_BP_PRIORITY", 0); return v; }
+int bp_priority_level() { static const int v = env_int("ZKP_HIP_BP_PRIORITY", 1); return v; }
+int stark_priority_level() { static const int v = env_int("ZKP_HIP_STARK_PRIORITY", 1); return v; }
 int g16_priority_level() { static const int v = env_int("ZKP_HIP_G16_PRIORITY", 2); return v; }
 
 int prof_begin(Device::KProf& K, hipStream_t st, hipEvent_t* e1) {
@@ -641,10 +648,13 @@ int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32
     prof_end(dev().prof[0], st, e1, D.adds_per_row * rows);
     return 0;
 }
+void launch_sum_ed(const ReduceView& R, uint32_t* sums, hipStream_t st) {
+    k_sum_t<EdMsm, ED_SUM_ROWS, ED_SUM_TB><<<dim3((R.rows + ED_SUM_ROWS - 1) / ED_SUM_ROWS, R.ntargets), ED_SUM_TB, 0, st>>>(R, sums);
+}
 int launch_reduce(const DevLayout& D, uint32_t rows, const uint32_t* partial, uint32_t* sums, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
     ReduceView R; R.rows = rows; R.ntargets = D.ntargets; R.partial = partial; R.target_chunk_begin = D.target_chunk_begin;
     R.enc = enc; R.out_off = out_off; R.out = out; R.corr = nullptr;
-    ZKP_TRACED("k_sum_t<EdMsm>", st, k_sum_t<EdMsm><<<dim3((rows + 63) / 64, D.ntargets), SUM_TB, 0, st>>>(R, sums));
+    ZKP_TRACED("k_sum_t<EdMsm>", st, launch_sum_ed(R, sums, st));
     ZKP_TRACED("k_encode", st, k_encode<<<dim3((rows + TW - 1) / TW, D.ntargets), TW, 0, st>>>(R, sums));
     return 0;
 }
@@ -1048,6 +1058,7 @@ int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t*
     uint64_t *d_in = nullptr; uint8_t *d_seeds = nullptr, *d_out = nullptr; uint32_t* d_len = nullptr; int32_t* d_status = nullptr;
     HIP_TRY(mem.alloc(&d_in, 24 * n)); HIP_TRY(mem.alloc(&d_seeds, 32 * n)); HIP_TRY(mem.alloc(&d_out, stride * n));
     HIP_TRY(mem.alloc(&d_len, 4 * n)); HIP_TRY(mem.alloc(&d_status, 4 * n));
+    trace_origin(st);
     HIP_TRY(hipMemcpyAsync(d_in, value, 8 * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_in + n, min, 8 * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_in + 2 * n, max, 8 * n, hipMemcpyHostToDevice, st));
@@ -1060,6 +1071,7 @@ int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t*
         HIP_TRY(hipMemcpyAsync(out_len, d_len, 4 * n, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(status, d_status, 4 * n, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        trace_dump();
         // a failed item leaves no proof bytes behind (reference returns Err, never a partial Vec)
         for (uint64_t i = 0; i < n; i++) if (status[i] != 0) memset(out + i * stride, 0, stride);
     }
