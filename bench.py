@@ -9,18 +9,25 @@ same batch through zkp_hip_process_batch with host buffers in and out (staging, 
 `host_buffers` -- it is never `value`.
 
 Multi-GPU: one process per GPU (the driver launches `python -m torch.distributed.run ... bench.py --gpus N`; a bare
-`python bench.py --gpus N` launches those children itself before anything touches the GPU).  Every rank proves its own
-4096-op batch (weak scaling: the ops are independent, there is no data-path exchange inside the proving) and the packed
-proofs of all ranks are gathered to every rank with one RCCL all_gather per step inside the timed region (what a node-level
-process_batch has to hand back); the gather of step k overlaps the proving of step k + 1 and all of them have landed before the
-clock stops.
+`python bench.py --gpus N` launches those children itself before anything touches the GPU).
+  * the contract's line (`value`, "scaling": "weak"): every rank proves its own 4096-op batch (the ops are independent, there is no
+    data-path exchange inside the proving) and the packed proofs of all ranks are gathered to every rank with one RCCL all_gather per
+    step inside the timed region; the gather of step k overlaps the proving of step k + 1 and all have landed before the clock stops.
+  * `strong_scaling_c5` (extra key, N > 1 or --force-dist): BASELINE config 5 itself -- ONE seeded 16 384-op mixed batch, rank r stages
+    the ops zkp_hip_plan_shards gives it (per-variant contiguous slices: every GPU runs the same kernel mix), proves them, and the
+    all_gather of the packed proofs is inside the clock, nothing overlapped: value = 16 384 x steps / wall.
+  * `in_library_shards` (extra key, N = 1 when the process sees several GPUs): the same 16 384-op batch through ONE process driving
+    every visible GPU (zkp_hip_init_devices + zkp_hip_process_batch), the form the reference's single Rust process would use.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
   roofline       the dominant kernel of the mixed batch, k_msm_gather<G1Msm> (Groth16 key-point MSMs), against the HBM roof
   roofline_valu  the same kernel against the VALU integer roof that actually binds it
   cpu_baseline   oracle/c's process_batch port (OpenMP over ops, like rayon) on a bounded sample of the same ops.
+The timed region runs with the library's per-launch event profiling OFF; the launch durations behind `roofline` come from a second
+pass of the same K steps with it on (`profiled_pass` holds that pass's step time: the cost of the instrumentation is visible).
 """
 import argparse
+import csv
 import ctypes
 import json
 import os
@@ -34,12 +41,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BATCH = 4096
+C5_BATCH = 16384
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md
 MAD_ISSUE_T = 35.157                     # T v_mad_u64_u32 lane-ops/s, isolated issue-rate measurement (profiles/r02_fe_microbench.json)
 MADS_PER_G1_MADD = 7 * 162 + 2 * 126 + 243      # g1_mmadd9 (XYZZ, nine 29-bit limbs): 7 products, 2 squarings, 1 fused double product (bn254_fq9.h)
 G1_BARE_LOOP_GADDS = 16.99               # G additions/s of the bare addition loop at 3 waves/SIMD, no loads (tools/g1_add_rate.hip, profiles/r02_g1_add_rate.jsonl)
 MADS_PER_ED_MADD = 7 * 100               # mixed addition with an affine-Niels entry: 7 GF(2^255-19) products of 100 mads
 ALGO_BYTES = {"range": 24 + 32 + 1478, "equality": 16 + 32 + 298, "membership16": 8 + 128 + 32 + 430}
+ALONE_CSV = os.path.join(ROOT, "profiles", "r03_kernel_alone.csv")      # per-kernel durations with every dispatch serialised (counter pass)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 
 def _free_port():
@@ -90,6 +100,15 @@ def cpu_baseline(sample, threads):
                       "process_batch port, OpenMP %d threads, %.1f s wall = %.0f core-seconds" % (sample, sample // 4, threads, dt, dt * threads)}
 
 
+def alone_durations():
+    """Average duration of a kernel with every dispatch serialised (profiles/r03_kernel_alone.csv, written by tools/kernel_alone.py from the
+    counter pass of tools/profile_round.sh): what the kernel takes when it has the GPU to itself."""
+    if not os.path.exists(ALONE_CSV):
+        return {}
+    with open(ALONE_CSV) as f:
+        return {r["kernel"]: {"avg_ms": float(r["avg_ms"]), "launches_per_step": float(r["launches_per_step"])} for r in csv.DictReader(f)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,8 +116,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs reported beside the contract's line (host buffers, C2/C3/C4 on their own)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs reported beside the contract's line (host buffers, C2/C3/C4 on their own, strong scaling, in-library shards)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, the driver's runs) or gloo (rehearsing N > 1 on a box with fewer GPUs)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed and run the gather path even at world size 1 (tests/test_gpu_rccl.py)")
+    ap.add_argument("--c5-batch", type=int, default=C5_BATCH, help="ops of the strong-scaling leg's one batch")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     args = ap.parse_args()
 
@@ -115,83 +136,112 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()) if world == 1 else "29500")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP prover has no CPU fallback")
     if os.environ.get("ZKP_BENCH_DEVICE") is not None:          # rehearsal only: several ranks on one GPU
         local_rank = int(os.environ["ZKP_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        if args.dist_backend == "nccl":
+    on_gpu = args.dist_backend == "nccl"
+    if use_dist:
+        if on_gpu:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    gdev = dev if on_gpu else torch.device("cpu")
 
     L = _native.lib()
     P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
     _native.check(L.zkp_hip_init(local_rank), "zkp_hip_init")
+    keys = []
     for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")):      # ONE trusted setup for every rank: the committed test keys
         blob = open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
+        keys.append((kind, blob))
         _native.check(L.zkp_hip_groth16_load_key(kind, blob, len(blob)), "zkp_hip_groth16_load_key")
 
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    class Gatherer:
+        """The node-level process_batch hands every proof back: all_gather of the ranks' packed proofs (device-resident results of the
+        staged batch `h`).  overlap = True: two buffer pairs, the gather of step k runs on RCCL's stream while step k + 1 is proved."""
+        def __init__(self, h, overlap):
+            cap = int(L.zkp_hip_batch_max_bytes(h))
+            caps = [torch.zeros(1, dtype=torch.int64, device=gdev) for _ in range(world)]
+            dist.all_gather(caps, torch.tensor([cap], dtype=torch.int64, device=gdev))
+            slot = max(int(c.item()) for c in caps)
+            nbuf = 2 if overlap else 1
+            self.h, self.overlap, self.n = h, overlap, 0
+            self.mine = [torch.zeros(slot, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+            self.all = [torch.zeros(world * slot, dtype=torch.uint8, device=gdev) for _ in range(nbuf)]
+            self.pending = [None] * nbuf
+
+        def gather(self):
+            b = self.n % len(self.mine); self.n += 1
+            if self.pending[b] is not None:
+                self.pending[b].wait()                                # this buffer pair was handed to the gather two steps ago
+            s = torch.cuda.current_stream()
+            _native.check(L.zkp_hip_batch_device_results(self.h, 0, self.mine[b].data_ptr(), self.mine[b].numel(), None, None, ctypes.c_void_p(s.cuda_stream)), "device_results")
+            if self.all[b].is_cuda:
+                w = dist.all_gather_into_tensor(self.all[b], self.mine[b], async_op=True)
+            else:
+                s.synchronize()
+                w = dist.all_gather_into_tensor(self.all[b], self.mine[b].cpu(), async_op=True)
+            if self.overlap:
+                self.pending[b] = w
+            else:
+                w.wait()
+
+        def drain(self):
+            for b in range(len(self.pending)):                       # every gather issued so far has landed before the clock is read
+                if self.pending[b] is not None:
+                    self.pending[b].wait(); self.pending[b] = None
+
+    # ------------------------------------------------------------------ the contract's line: one 4096-op batch per rank
     n = args.batch
     ops, lists, seeds = wl.mixed_ops(n, 5 + rank)
     counts = {k: int((ops["kind"] == c).sum()) for k, c in (("range", 1), ("equality", 2), ("membership", 4), ("improvement", 5))}
     h = ctypes.c_void_p()
     _native.check(L.zkp_hip_batch_stage(n, P(ops), P(lists), P(seeds), ctypes.byref(h)), "zkp_hip_batch_stage")      # inputs resident in HBM from here on
     cap = int(L.zkp_hip_batch_max_bytes(h))
-    gathered = mine = None
-    if world > 1:
-        caps = [torch.zeros(1, dtype=torch.int64, device=dev if args.dist_backend == "nccl" else "cpu") for _ in range(world)]
-        dist.all_gather(caps, torch.tensor([cap], dtype=torch.int64, device=caps[0].device))
-        slot = max(int(c.item()) for c in caps)
-        gdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
-        # two sets of buffers: the gather of step k runs (RCCL's own stream) while step k + 1 is being proved
-        mine = [torch.zeros(slot, dtype=torch.uint8, device=dev) for _ in range(2)]
-        gathered = [torch.zeros(world * slot, dtype=torch.uint8, device=gdev) for _ in range(2)]
-    pending = [None, None]
-    nstep = [0]
+    G = Gatherer(h, overlap=True) if use_dist else None
 
     def step():
         _native.check(L.zkp_hip_batch_prove(h), "zkp_hip_batch_prove")
-        if world > 1:                                                # the node-level process_batch hands every proof back: gather the packed proofs
-            b = nstep[0] & 1; nstep[0] += 1
-            if pending[b] is not None:
-                pending[b].wait()                                    # this buffer pair was handed to the gather two steps ago
-            s = torch.cuda.current_stream()
-            _native.check(L.zkp_hip_batch_device_results(h, 0, mine[b].data_ptr(), mine[b].numel(), None, None, ctypes.c_void_p(s.cuda_stream)), "device_results")
-            if gathered[b].is_cuda:
-                pending[b] = dist.all_gather_into_tensor(gathered[b], mine[b], async_op=True)
-            else:
-                s.synchronize()
-                pending[b] = dist.all_gather_into_tensor(gathered[b], mine[b].cpu(), async_op=True)
+        if G is not None:
+            G.gather()
 
-    def barrier():
-        for b in range(2):                                           # every gather issued so far has landed before the clock is read
-            if pending[b] is not None:
-                pending[b].wait(); pending[b] = None
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def timed_steps(k):
+        ms = []
+        t0 = time.perf_counter()
+        for _ in range(k):
+            ts = time.perf_counter()
+            step()
+            ms.append((time.perf_counter() - ts) * 1e3)
+        if G is not None:
+            G.drain()
+        barrier()
+        return time.perf_counter() - t0, ms
 
     for _ in range(args.warmup):
         step()
+    if G is not None:
+        G.drain()
     barrier()
+    dt, step_ms = timed_steps(args.steps)                            # the timed region: no instrumentation inside the library
+
+    # second pass, same K steps, with an event pair around every MSM launch: the launch durations behind `roofline`
     L.zkp_hip_profile_enable(1)
     for k in range(3):
         L.zkp_hip_profile_read_kernel(k, None, None, None, 1)
-    step_ms = []
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        ts = time.perf_counter()
-        step()
-        step_ms.append((time.perf_counter() - ts) * 1e3)
-    barrier()
-    dt = time.perf_counter() - t0
+    dt_prof, _ = timed_steps(args.steps)
     prof = []
     for k in range(3):
         ms, launches, adds = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
@@ -209,13 +259,16 @@ def main():
 
     extra = {}
     under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-    if world == 1 and not args.no_extra_legs and not under_profiler:    # N = 1 only; a profile of this command holds the timed steps only
-        def timed(f, reps):
-            f()
-            ts = []
-            for _ in range(reps):
-                t = time.perf_counter(); f(); ts.append(time.perf_counter() - t)
-            return statistics.median(ts)
+    legs = not args.no_extra_legs and not under_profiler               # a profile of this command holds the contract's steps only
+
+    def timed(f, reps):
+        f()
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter(); f(); ts.append(time.perf_counter() - t)
+        return statistics.median(ts)
+
+    if world == 1 and legs and not args.force_dist:
         hb_off = np.zeros(n + 1, dtype=np.uint64); hb_st = np.zeros(n, dtype=np.int32)
         t_hb = timed(lambda: _native.check(L.zkp_hip_process_batch(n, P(ops), P(lists), P(seeds), P(out), cap, P(hb_off), P(hb_st)), "process_batch"), 8)
         # two batches in flight (zkp_hip_batch_prove_async on two staged copies of the batch, alternately): how a server that feeds
@@ -236,19 +289,78 @@ def main():
                                           "note": "the same K steps launched with zkp_hip_batch_prove_async on two staged batches alternately; not the contract's value"}
         extra["host_buffers"] = {"value": n / t_hb, "unit": "proofs/s", "ms_per_batch": t_hb * 1e3,
                                  "note": "the same batch through zkp_hip_process_batch: bucketing + validation + pinned staging + H2D + proving + D2H of %d proof bytes; not `value`" % out_bytes}
-        legs = {}
+        other = {}
         for name, gen, cnt in (("C2_range_4096", wl.range_ops, 4096), ("C3_equality_4096", wl.equality_ops, 4096), ("C4_improvement_1024", wl.improvement_ops, 1024)):
             o2, l2, s2 = gen(cnt)
             h2 = ctypes.c_void_p()
             _native.check(L.zkp_hip_batch_stage(cnt, P(o2), P(l2), P(s2), ctypes.byref(h2)), "stage")
             t = timed(lambda: _native.check(L.zkp_hip_batch_prove(h2), "prove"), 5)
             L.zkp_hip_batch_free(h2)
-            legs[name] = {"proofs_per_s": cnt / t, "ms_per_batch": t * 1e3}
-        extra["other_configs_staged"] = legs
+            other[name] = {"proofs_per_s": cnt / t, "ms_per_batch": t * 1e3}
+        extra["other_configs_staged"] = other
     L.zkp_hip_batch_free(h)
 
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+    # ------------------------------------------------------------------ BASELINE config 5: ONE 16 384-op batch sharded over the ranks
+    if use_dist and legs:
+        nt = args.c5_batch
+        ops5, lists5, seeds5 = wl.mixed_ops(nt, 5)                        # the same batch on every rank
+        owner = np.zeros(nt, dtype=np.uint32)
+        _native.check(L.zkp_hip_plan_shards(nt, P(ops5), world, P(owner)), "zkp_hip_plan_shards")
+        mine_ix = np.nonzero(owner == rank)[0]
+        my_ops = ops5[mine_ix].copy()                                      # list_off still indexes the shared `lists5`
+        my_seeds = np.ascontiguousarray(seeds5.reshape(nt, 32)[mine_ix]).ravel()
+        h5 = ctypes.c_void_p()
+        _native.check(L.zkp_hip_batch_stage(len(my_ops), P(my_ops), P(lists5), P(my_seeds), ctypes.byref(h5)), "stage (strong)")
+        G5 = Gatherer(h5, overlap=False)
+
+        def step5():
+            _native.check(L.zkp_hip_batch_prove(h5), "zkp_hip_batch_prove")
+            G5.gather()                                                    # blocking: every rank holds every proof when the step ends
+
+        for _ in range(max(1, args.warmup)):
+            step5()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step5()
+        barrier()
+        dt5 = time.perf_counter() - t0
+        c5 = np.zeros(len(my_ops), dtype=np.int32); o5 = np.zeros(len(my_ops) + 1, dtype=np.uint64); b5 = np.zeros(int(L.zkp_hip_batch_max_bytes(h5)), dtype=np.uint8)
+        assert _native.check(L.zkp_hip_batch_fetch(h5, P(b5), b5.size, P(o5), P(c5)), "fetch (strong)") == 0 and not c5.any()
+        L.zkp_hip_batch_free(h5)
+        t5 = torch.tensor([dt5], dtype=torch.float64, device=gdev)
+        dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+        dt5 = float(t5.item())
+        extra["strong_scaling_c5"] = {"value": nt * args.steps / dt5, "unit": "proofs/s", "ms_per_step": dt5 / args.steps * 1e3, "scaling": "strong", "n_gpus": world,
+                                      "ops_in_the_one_batch": nt, "ops_on_rank_0": int(len(my_ops)),
+                                      "note": "BASELINE config 5: one seeded %d-op mixed batch, per-variant contiguous slices from zkp_hip_plan_shards, each rank proves its slice, "
+                                              "blocking all_gather of the packed proofs inside the clock (max over ranks); not the contract's value" % nt}
+
+    # ------------------------------------------------------------------ one process driving every visible GPU (the in-library multi-GPU path)
+    ngpu = torch.cuda.device_count()
+    if world == 1 and legs and not args.force_dist and (ngpu > 1 or os.environ.get("ZKP_BENCH_SHARDS")):
+        devices = [int(x) for x in os.environ["ZKP_BENCH_SHARDS"].split(",")] if os.environ.get("ZKP_BENCH_SHARDS") else list(range(ngpu))
+        L.zkp_hip_shutdown()
+        _native.init_devices(devices)
+        for kind, blob in keys:
+            _native.check(L.zkp_hip_groth16_load_key(kind, blob, len(blob)), "zkp_hip_groth16_load_key")
+        nt = args.c5_batch
+        ops5, lists5, seeds5 = wl.mixed_ops(nt, 5)
+        h5 = ctypes.c_void_p()
+        _native.check(L.zkp_hip_batch_stage(nt, P(ops5), P(lists5), P(seeds5), ctypes.byref(h5)), "stage (in-library shards)")
+        t_st = timed(lambda: _native.check(L.zkp_hip_batch_prove(h5), "prove"), max(3, args.steps // 4))
+        cap5 = int(L.zkp_hip_batch_max_bytes(h5))
+        b5 = np.zeros(cap5, dtype=np.uint8); o5 = np.zeros(nt + 1, dtype=np.uint64); c5 = np.zeros(nt, dtype=np.int32)
+        assert _native.check(L.zkp_hip_batch_fetch(h5, P(b5), cap5, P(o5), P(c5)), "fetch") == 0 and not c5.any()
+        L.zkp_hip_batch_free(h5)
+        t_hb5 = timed(lambda: _native.check(L.zkp_hip_process_batch(nt, P(ops5), P(lists5), P(seeds5), P(b5), cap5, P(o5), P(c5)), "process_batch"), 3)
+        extra["in_library_shards"] = {"devices": devices, "ops_in_the_one_batch": nt, "staged": {"value": nt / t_st, "unit": "proofs/s", "ms_per_batch": t_st * 1e3},
+                                      "host_buffers": {"value": nt / t_hb5, "unit": "proofs/s", "ms_per_batch": t_hb5 * 1e3},
+                                      "note": "one process, zkp_hip_init_devices(%d shards), one host worker thread per shard; the %d-op C5 batch cut into per-variant contiguous "
+                                              "slices; not the contract's value" % (len(devices), nt)}
+
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -257,17 +369,26 @@ def main():
         ed, g1, g2 = prof
         g1_avg_ms = g1[0] / max(1, g1[1])
         # algorithmic bytes one G1 MSM launch must move: an equality launch serves its 346 B/proof ops, a membership
-        # launch its 598 B/proof ops; the steps alternate one of each, so the per-launch average is the mean of the two
-        # (the G1 MSM of a circuit is two launches since the split pipeline -- A/B1 and the l/h sum -- each credited half)
+        # launch its 598 B/proof ops; the G1 MSM of a circuit is two launches (A/B1 and the l/h sum), each credited half
         g1_launches_per_step = max(1.0, g1[1] / max(1, args.steps))
         algo_launch = (ALGO_BYTES["equality"] * counts["equality"] + ALGO_BYTES["membership16"] * counts["membership"]) / g1_launches_per_step
         achieved = algo_launch / (g1_avg_ms * 1e-3) / 1e9 if g1_avg_ms > 0 else 0.0
         g1_mad_rate = g1[2] * MADS_PER_G1_MADD / (g1[0] * 1e-3) / 1e12 if g1[0] > 0 else 0.0        # T mad/s
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
+        if os.path.exists(TRAFFIC_JSON):
+            tj = json.load(open(TRAFFIC_JSON))
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
+        alone = alone_durations()
+        a_g1 = alone.get("k_msm_gather<G1Msm>")
+        adds_per_launch = g1[2] / max(1, g1[1])
+        alone_valu = None
+        if a_g1:
+            rate = adds_per_launch * MADS_PER_G1_MADD / (a_g1["avg_ms"] * 1e-3) / 1e12
+            alone_valu = {"avg_launch_ms": a_g1["avg_ms"], "achieved": rate, "frac": rate / MAD_ISSUE_T,
+                          "g_additions_per_s": adds_per_launch / (a_g1["avg_ms"] * 1e-3) / 1e9,
+                          "fraction_of_bare_loop": adds_per_launch / (a_g1["avg_ms"] * 1e-3) / 1e9 / G1_BARE_LOOP_GADDS,
+                          "hbm_frac": algo_launch / (a_g1["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "source": "profiles/r03_kernel_alone.csv"}
+        floor = sum(v["avg_ms"] * v["launches_per_step"] for k, v in alone.items() if k in ("k_msm_gather<G1Msm>", "k_msm_gather<G2Msm>", "k_msm_dma<EdMsm>", "k_g16_qap", "k_stark_prove"))
         res = {
             "metric": "proofs/sec (whole node) + ms/proof p50, 4096-proof mixed batch (range / equality / membership / improvement) per MI355X",
             "value": total / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -276,24 +397,29 @@ def main():
             "config": {"workload": "process_batch of %d mixed ops, i mod 4 = prove_range(v,0,2^32) / prove_equality / prove_membership(16-element set) / "
                                    "prove_improvement, seed 5 (BASELINE.md C5's mix at the metric's 4096-op size)" % n,
                        "ops_per_gpu_per_step": n, "ops_by_variant": counts, "proof_bytes_per_step": out_bytes,
-                       "timed_region": "zkp_hip_batch_prove on a batch staged in HBM; packed proofs + offsets left in HBM"
-                                       + ("; RCCL all_gather of every rank's packed proofs, overlapped with the next step's proving, all landed before the clock stops" if world > 1 else ""),
+                       "timed_region": "zkp_hip_batch_prove on a batch staged in HBM; packed proofs + offsets left in HBM; no profiling inside the library"
+                                       + ("; RCCL all_gather of every rank's packed proofs, overlapped with the next step's proving, all landed before the clock stops" if use_dist else ""),
                        "sharding": "independent ops, one 4096-op batch per rank, no exchange inside the proving"},
             "ms_per_proof_p50": statistics.median(step_ms) / n,
             "ms_per_batch_p50": statistics.median(step_ms),
+            "profiled_pass": {"ms_per_step": dt_prof / args.steps * 1e3, "note": "the same K steps again with an event pair around every MSM launch (zkp_hip_profile_enable): "
+                                                                              "the source of the launch durations below; its step time shows what the instrumentation costs"},
+            "kernel_floor_ms_per_step": floor if floor else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_msm_gather<G1Msm>",
                          "avg_launch_ms": g1_avg_ms, "launches": g1[1], "algorithmic_bytes_per_launch": algo_launch,
-                         "share_of_step": g1[0] / (dt * 1e3) if world == 1 else None,
+                         "share_of_step": g1[0] / (dt_prof * 1e3) if world == 1 else None,
                          "note": "integer-ALU-bound kernel (SURVEY 8d): see roofline_valu; launch durations are taken on the kernel's own stream while the "
                                  "other variants' kernels share the GPU"},
             "roofline_valu": {"bound": "valu-int", "achieved": g1_mad_rate, "peak": MAD_ISSUE_T, "unit": "T v_mad_u64_u32/s", "frac": g1_mad_rate / MAD_ISSUE_T,
                               "kernel": "k_msm_gather<G1Msm>", "point_additions_per_step": g1[2] / max(1, args.steps), "mads_per_point_addition": MADS_PER_G1_MADD,
                               "g_additions_per_s": g1[2] / (g1[0] * 1e-3) / 1e9 if g1[0] > 0 else 0.0,
                               "fraction_of_bare_loop": (g1[2] / (g1[0] * 1e-3) / 1e9 / G1_BARE_LOOP_GADDS) if g1[0] > 0 else 0.0,
+                              "alone": alone_valu,
                               "peak_source": "profiles/r02_fe_microbench.json: isolated v_mad_u64_u32 issue rate (the multiply-adds of the field products only; "
                                              "carries, masks and loads share the same issue slots: a pure product chain reaches 75 % of it, the bare addition loop "
-                                             "(profiles/r02_g1_add_rate.jsonl) 75 %); launch durations are taken while the other variants' kernels share the GPU"},
+                                             "(profiles/r02_g1_add_rate.jsonl) 75 %); launch durations are taken while the other variants' kernels share the GPU, "
+                                             "`alone` from the serialised counter pass"},
             "other_msm_kernels": {
                 "k_msm_gather<G2Msm>": {"avg_launch_ms": g2[0] / max(1, g2[1]), "launches": g2[1], "ms_per_step": g2[0] / max(1, args.steps),
                                         "point_additions_per_step": g2[2] / max(1, args.steps), "g_additions_per_s": g2[2] / (g2[0] * 1e-3) / 1e9 if g2[0] > 0 else None,
@@ -303,11 +429,11 @@ def main():
                                      "valu_frac": (ed[2] * MADS_PER_ED_MADD / (ed[0] * 1e-3) / 1e12 / MAD_ISSUE_T) if ed[0] > 0 else None}},
         }
         res.update(extra)
-        if world == 1 and not args.no_cpu_baseline:                 # the contract: rank 0 at N = 1 only
+        if world == 1 and not args.no_cpu_baseline and not args.force_dist:      # the contract: rank 0 at N = 1 only
             threads = min(len(os.sched_getaffinity(0)), 32)
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample, threads)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     L.zkp_hip_shutdown()

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Per-kernel durations with every dispatch SERIALISED (what a kernel takes with the GPU to itself), from the kernel trace of a
+rocprofv3 counter pass (`--pmc` passes run one dispatch at a time).  Writes the CSV bench.py reads for `roofline_valu.alone` and
+`kernel_floor_ms_per_step`.  Usage: kernel_alone.py p_kernel_trace.csv OUT.csv   (steps are counted by k_batch_pack dispatches)"""
+import csv
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0].replace(", 8u, 256u, 1u", "").replace(", 32u, 256u, 1u", "").strip()
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for r in csv.DictReader(open(src)):
+        k = short(r["Kernel_Name"])
+        tot[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        cnt[k] += 1
+    steps = max(1, cnt.get("k_batch_pack", 1))
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "avg_ms", "launches_per_step", "ms_per_step", "launches"])
+        for k in sorted(tot, key=lambda k: -tot[k]):
+            if k.startswith("k_g16_build_table") or k.startswith("__amd"):
+                continue                                      # key load / runtime copies: not part of a step
+            w.writerow([k, "%.4f" % (tot[k] / cnt[k]), "%.3f" % (cnt[k] / steps), "%.4f" % (tot[k] / steps), cnt[k]])
+    print("wrote %s: %d kernels over %d steps" % (out, len(tot), steps))
+
+
+if __name__ == "__main__":
+    main()
