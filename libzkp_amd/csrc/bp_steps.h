@@ -176,6 +176,8 @@ struct MsmView {
     uint32_t* partial;           // [nchunks][40][rows]
     const uint32_t* acc_init;    // optional [ACC_W]: every chunk's accumulator starts from this point (Weierstrass MSMs: a
                                  // fixed offset point so the unchecked mixed addition never sees infinity); nullptr = identity
+    uint32_t nwin = 0, nent = 0, digw = 0;      // k_msm_gather only: shape of the table behind `table` (windows per point, entries per
+                                                // window, digit words per scalar) -- a run-time property of the loaded Groth16 key
 };
 ZKP_HD inline void msm_chunk_ref(const MsmView& m, uint32_t chunk, uint32_t row) {
     ge acc = ge_identity();

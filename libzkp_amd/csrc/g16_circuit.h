@@ -26,11 +26,14 @@ struct HostLC { std::map<uint32_t, fr> t; };       // column -> coefficient
 struct HostR1CS {
     uint32_t n_inst = 1, n_wit = 0;
     std::vector<std::array<HostLC, 3>> rows;
-    std::vector<uint8_t> inst_nwin{1}, wit_nwin;   // windows a variable's scalar can occupy
+    std::vector<uint8_t> inst_nwin{1}, wit_nwin;   // windows a variable's scalar can occupy: a literal count, or one of the two classes below
     uint32_t new_input(uint8_t nwin) { inst_nwin.push_back(nwin); return n_inst++; }
     uint32_t new_witness(uint8_t nwin) { wit_nwin.push_back(nwin); return 0x80000000u | n_wit++; }
 };
 constexpr uint32_t WIT = 0x80000000u;
+// size classes of a variable's scalar; the window count follows from the radix of the key's tables when the key is loaded
+constexpr uint8_t G16_NW_FULL = 0xFF, G16_NW_U64 = 0xFE;
+inline uint8_t g16_class_nwin(uint8_t cls, const G16Radix& rx) { return cls == G16_NW_FULL ? (uint8_t)rx.nwin : cls == G16_NW_U64 ? (uint8_t)rx.nwin_u64 : cls; }
 inline HostLC lc_var(uint32_t v) { HostLC l; l.t[v] = fp_one<FrParams>(); return l; }
 inline HostLC lc_add(const HostLC& a, const HostLC& b) {
     HostLC o = a;
@@ -64,29 +67,29 @@ inline HostLC r1cs_mimc(HostR1CS& cs, HostLC x) {                   // snark.rs:
     ensure_mimc_constants();
     for (uint32_t i = 0; i < MIMC_ROUNDS; i++) {
         const HostLC t = lc_add(x, lc_scale(lc_var(VAR_ONE), g_mimc_host[i]));
-        const uint32_t t2 = r1cs_mul(cs, t, t, G16_NWIN);
-        const uint32_t t4 = r1cs_mul(cs, lc_var(t2), lc_var(t2), G16_NWIN);
-        x = lc_var(r1cs_mul(cs, lc_var(t4), t, G16_NWIN));
+        const uint32_t t2 = r1cs_mul(cs, t, t, G16_NW_FULL);
+        const uint32_t t4 = r1cs_mul(cs, lc_var(t2), lc_var(t2), G16_NW_FULL);
+        x = lc_var(r1cs_mul(cs, lc_var(t4), t, G16_NW_FULL));
     }
     return x;
 }
 inline HostR1CS build_equality_r1cs() {                              // snark.rs:262-291
     HostR1CS cs;
-    const uint32_t a = cs.new_witness(G16_NWIN_U64), b = cs.new_witness(G16_NWIN_U64);
+    const uint32_t a = cs.new_witness(G16_NW_U64), b = cs.new_witness(G16_NW_U64);
     r1cs_enforce_equal(cs, lc_var(a), lc_var(b));
     const HostLC h = r1cs_mimc(cs, lc_var(a));
-    const uint32_t c = cs.new_input(G16_NWIN);
+    const uint32_t c = cs.new_input(G16_NW_FULL);
     r1cs_enforce_equal(cs, h, lc_var(c));
     return cs;
 }
 inline HostR1CS build_membership_r1cs() {                            // snark.rs:514-585
     HostR1CS cs;
-    const uint32_t v = cs.new_witness(G16_NWIN_U64);
+    const uint32_t v = cs.new_witness(G16_NW_U64);
     const HostLC h = r1cs_mimc(cs, lc_var(v));
-    const uint32_t c = cs.new_input(G16_NWIN);
+    const uint32_t c = cs.new_input(G16_NW_FULL);
     r1cs_enforce_equal(cs, h, lc_var(c));
     std::vector<uint32_t> setv, real, sel;
-    for (uint32_t i = 0; i < G16_MAX_SET; i++) setv.push_back(cs.new_input(G16_NWIN_U64));
+    for (uint32_t i = 0; i < G16_MAX_SET; i++) setv.push_back(cs.new_input(G16_NW_U64));
     for (uint32_t i = 0; i < G16_MAX_SET; i++) { const uint32_t b = cs.new_input(1); cs.rows.push_back({lc_sub(lc_var(VAR_ONE), lc_var(b)), lc_var(b), HostLC{}}); real.push_back(b); }
     for (uint32_t i = 0; i < G16_MAX_SET; i++) { const uint32_t b = cs.new_witness(1); cs.rows.push_back({lc_sub(lc_var(VAR_ONE), lc_var(b)), lc_var(b), HostLC{}}); sel.push_back(b); }
     HostLC total;
@@ -97,7 +100,7 @@ inline HostR1CS build_membership_r1cs() {                            // snark.rs
     }
     r1cs_enforce_equal(cs, total, lc_var(VAR_ONE));
     HostLC acc;
-    for (uint32_t i = 0; i < G16_MAX_SET; i++) acc = lc_add(acc, lc_var(r1cs_mul(cs, lc_var(sel[i]), lc_sub(lc_var(v), lc_var(setv[i])), G16_NWIN)));
+    for (uint32_t i = 0; i < G16_MAX_SET; i++) acc = lc_add(acc, lc_var(r1cs_mul(cs, lc_var(sel[i]), lc_sub(lc_var(v), lc_var(setv[i])), G16_NW_FULL)));
     r1cs_enforce_equal(cs, acc, HostLC{});
     return cs;
 }

@@ -2,9 +2,8 @@
 #include "g16_launch.h"
 #include "msm_kernel.h"
 
-struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b1/h/l queries)
-    static constexpr uint32_t AFF_W = 20, ACC_W = G1_JAC_W, MIN_WAVES = 4, TB = 1024, NWIN = G16_NWIN, NENT = G16_NENT, DIGW = G16_DIGW, DIG_PER_WORD = 2;
-    static constexpr bool DOUBLE_BUF = true;                      // 2 x 40 KB sub-table images, one 1024-lane workgroup per CU
+struct G1Msm {      // BN254 G1 key points (Groth16 a / b1 / h / l queries): packed affine table entries, XYZZ accumulator
+    static constexpr uint32_t ACC_W = G1_JAC_W, DIG_PER_WORD = 2;
     static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int16_t)(word >> (16 * (w & 1u))); }
     using Acc = g1_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq>(); }
@@ -24,23 +23,16 @@ struct G1Msm {      // BN254 G1 affine tables, Jacobian accumulator (Groth16 a/b
         q.y = fq9_select(d < 0, fq9_neg_k<4>(q.y), q.y);                 // entries are < 3p
         return g1_mmadd9(acc, q);
     }
-    static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {      // LDS A/B build
-        const uint32_t* e = subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W;
-        g1_aff q; ZKP_UNROLL for (int k = 0; k < 10; k++) { q.x.v[k] = e[k]; q.y.v[k] = e[10 + k]; }
-        q.y = fq_select(d < 0, fq_sub_k4(fq_zero(), q.y), q.y);
-        return g1_madd_lazy(acc, q);
-    }
     static __device__ __forceinline__ void store(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const Acc& a) { st_g1_jac(p, idx, row, rows, a); }
     static __device__ __forceinline__ Acc load(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) { return ld_g1_jac(p, idx, row, rows); }
     static __device__ __forceinline__ Acc add(const Acc& a, const Acc& b) { return jac_add(a, b); }
 };
 struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
-    static constexpr uint32_t AFF_W = 40, ACC_W = G2_JAC_W, MIN_WAVES = 2, TB = 512, NWIN = G16_NWIN, NENT = G16_NENT, DIGW = G16_DIGW, DIG_PER_WORD = 2;
-    static constexpr bool DOUBLE_BUF = false;                     // one 80 KB image (two would need all 160 KB of LDS); 512 lanes = 2 waves/SIMD at 256 VGPRs
+    static constexpr uint32_t ACC_W = G2_JAC_W, DIG_PER_WORD = 2;
     static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int16_t)(word >> (16 * (w & 1u))); }
     using Acc = g2_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq2>(); }
-    static constexpr uint32_t GATHER_WAVES = 2; static constexpr int GATHER_PREFETCH = 0;     // k_msm_gather: the addition itself takes 243 VGPRs, entries are fetched at use
+    static constexpr uint32_t GATHER_WAVES = 2; static constexpr int GATHER_PREFETCH = 0;     // k_msm_gather: the addition itself takes 239 VGPRs, entries are fetched at use
     // the gather loop: XYZZ coordinates over Fq2 on nine 29-bit limbs (bn254_g.h: g2_mmadd9); table entries are the four
     // coordinates x.c0, x.c1, y.c0, y.c1 packed into eight words each: 128 bytes, one cache line
     static constexpr uint32_t GATHER_W = 32;
@@ -50,13 +42,6 @@ struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
     static __device__ __forceinline__ GAcc accumulate_entry(const GAcc& acc, int32_t d, const uint32_t* e) {
         const g2_aff9 q{fq2_9{fq9_unpack8(e), fq9_unpack8(e + 8)}, fq2_9{fq9_unpack8(e + 16), fq9_unpack8(e + 24)}};
         return g2_mmadd9(acc, q, d < 0);
-    }
-    static __device__ __forceinline__ Acc accumulate_entry(const Acc& acc, int32_t d, const uint32_t* e) {      // ten-limb entries (LDS A/B build)
-        g2_aff q; ZKP_UNROLL for (int k = 0; k < 10; k++) { q.x.c0.v[k] = e[k]; q.x.c1.v[k] = e[10 + k]; q.y.c0.v[k] = e[20 + k]; q.y.c1.v[k] = e[30 + k]; }
-        return g2_madd_lazy(acc, q, d < 0);
-    }
-    static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) {
-        return accumulate_entry(acc, d, subtab + (size_t)((d < 0 ? -d : d) - 1) * AFF_W);
     }
     static __device__ __forceinline__ void store(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const Acc& a) { st_g2_jac(p, idx, row, rows, a); }
     static __device__ __forceinline__ Acc load(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) { return ld_g2_jac(p, idx, row, rows); }
@@ -99,16 +84,22 @@ __global__ void __launch_bounds__(TW) k_mimc_commit(const uint64_t* values, uint
     uint32_t w[8]; fp_to_raw(w, h);
     g16_put_bytes(out + 32ull * i, w, 8);
 }
-// thread = (slot, window): entries e = 1..NENT of 2^(WBITS window) * Base as affine points (Montgomery coordinates).  The
-// multiples are produced in Jacobian form eight at a time and converted with ONE field inversion per eight (Montgomery's
-// trick), which is what keeps a 4096-entry sub-table affordable at key load.
+// Window tables of key points: entry e (1-based) of window w of point P is e * 2^(wbits w) * P in affine form.
+// thread = (point, window, segment of SEG entries): the thread doubles P up to its window's power Q, steps to the first multiple of its
+// segment ((seg SEG + 1) Q, a short double-and-add), then walks the segment by repeated Jacobian additions of Q, eight entries
+// at a time with ONE field inversion per eight (Montgomery's trick).  Segments are what makes a key load short: with one thread per
+// (point, window) -- round 2 -- a 8192-entry window was a serial chain of 8192 additions on a GPU holding only ~30 000 such threads
+// (1.2 s per table, 2.4 s for both circuits); 512-entry segments give 16 times the threads and a sixteenth of the chain.
+// fmt9: entries in the MSM loops' form (nine 29-bit limbs per Fq coordinate, < 2.4 p, packed into eight words: 64 / 128 bytes);
+// otherwise plain ten-limb coordinates (the verifier's gamma_abc_g1 tables, g16_verify.h).
+constexpr uint32_t G16_TABLE_SEG = 512;
 template <class F, uint32_t AFF_W>
-__global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, uint32_t nslots, uint32_t* table, uint32_t fmt9) {
+__global__ void __launch_bounds__(TW, 2) k_g16_build_table(const uint32_t* bases, uint32_t nslots, uint32_t* table, uint32_t fmt9, G16Radix rx) {
+    const uint32_t seg_len = rx.nent < G16_TABLE_SEG ? rx.nent : G16_TABLE_SEG, nseg = rx.nent / seg_len;
     const uint32_t t = blockIdx.x * TW + threadIdx.x;
-    if (t >= nslots * G16_NWIN) return;
-    const uint32_t slot = t / G16_NWIN, win = t % G16_NWIN;
+    if (t >= nslots * rx.nwin * nseg) return;
+    const uint32_t seg = t % nseg, win = (t / nseg) % rx.nwin, slot = t / (nseg * rx.nwin);
     constexpr uint32_t FW = AFF_W / 2, BATCH = 8;
-    static_assert(G16_NENT % BATCH == 0, "entries per sub-table must be a multiple of the inversion batch");
     Aff<F> base;
     {
         const uint32_t* b = bases + (size_t)slot * AFF_W;
@@ -116,12 +107,18 @@ __global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, u
         for (uint32_t k = 0; k < FW; k++) { bx[k] = b[k]; by[k] = b[FW + k]; }
     }
     Jac<F> q = jac_from_aff(base);
-    for (uint32_t i = 0; i < G16_WBITS * win; i++) q = jac_dbl(q);
+    for (uint32_t i = 0; i < rx.wbits * win; i++) q = jac_dbl(q);
+    // acc = (seg * seg_len + 1) q: binary ladder over the segment's first index (at most wbits - 1 bits)
     Jac<F> acc = q;
+    {
+        const uint32_t first = seg * seg_len + 1;
+        int top = 31; while (top > 0 && !((first >> top) & 1u)) top--;
+        for (int b = top - 1; b >= 0; b--) { acc = jac_dbl(acc); if ((first >> b) & 1u) acc = jac_add(acc, q); }
+    }
     constexpr uint32_t NC = AFF_W / 10;                      // Fq coordinates per entry
     const uint32_t OW = fmt9 ? 8 * NC : AFF_W;             // words per stored entry
-    uint32_t* dst = table + ((size_t)slot * G16_NWIN + win) * G16_NENT * OW;
-    for (uint32_t e0 = 0; e0 < G16_NENT; e0 += BATCH) {
+    uint32_t* dst = table + (((size_t)slot * rx.nwin + win) * rx.nent + (size_t)seg * seg_len) * OW;
+    for (uint32_t e0 = 0; e0 < seg_len; e0 += BATCH) {
         Jac<F> pts[BATCH]; F zp[BATCH];
         for (uint32_t k = 0; k < BATCH; k++) {
             pts[k] = acc; acc = jac_add(acc, q);
@@ -137,7 +134,7 @@ __global__ void __launch_bounds__(TW) k_g16_build_table(const uint32_t* bases, u
             uint32_t* o = dst + (size_t)(e0 + k) * OW;
             if (fmt9) {                                            // the MSM loops' form: nine 29-bit limbs per Fq coordinate (< 2.4 p), packed
                 const fq* c = reinterpret_cast<const fq*>(&a);     // x then y (G1) / x.c0, x.c1, y.c0, y.c1 (G2)
-                for (uint32_t t = 0; t < NC; t++) fq9_pack8(o + 8 * t, fq9_from_fq(c[t]));
+                for (uint32_t t2 = 0; t2 < NC; t2++) fq9_pack8(o + 8 * t2, fq9_from_fq(c[t2]));
                 continue;
             }
             for (uint32_t j = 0; j < FW; j++) { o[j] = ax[j]; o[FW + j] = ay[j]; }
@@ -155,15 +152,13 @@ __global__ void __launch_bounds__(TW) k_g16_serialize(bool g2, const uint32_t* j
     else { uint32_t w[32]; g2_serialize(w, ld_g2_jac(jac, 0, row, rows)); g16_put_bytes(out + 128ull * row, w, 32); }
 }
 
-template __global__ void k_msm_dma<G1Msm>(MsmView, uint32_t, uint32_t);
-template __global__ void k_msm_dma<G2Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_msm_gather<G1Msm>(MsmView, uint32_t, uint32_t);
 template __global__ void k_msm_gather<G2Msm>(MsmView, uint32_t, uint32_t);
 static constexpr uint32_t G16_SUM_ROWS = 8, G16_SUM_TB = 256;         // 32 slices per row (msm_kernel.h)
 template __global__ void k_sum_t<G1Msm, G16_SUM_ROWS, G16_SUM_TB>(ReduceView, uint32_t*);
 template __global__ void k_sum_t<G2Msm, G16_SUM_ROWS, G16_SUM_TB>(ReduceView, uint32_t*);
-template __global__ void k_g16_build_table<fq, 20>(const uint32_t*, uint32_t, uint32_t*, uint32_t);
-template __global__ void k_g16_build_table<fq2, 40>(const uint32_t*, uint32_t, uint32_t*, uint32_t);
+template __global__ void k_g16_build_table<fq, 20>(const uint32_t*, uint32_t, uint32_t*, uint32_t, G16Radix);
+template __global__ void k_g16_build_table<fq2, 40>(const uint32_t*, uint32_t, uint32_t*, uint32_t, G16Radix);
 
 // ================================================================================================ launchers
 void g16_launch_witness(const G16View& V, hipStream_t st) { k_g16_witness<<<(V.rows + TW - 1) / TW, TW, 0, st>>>(V); }
@@ -182,35 +177,21 @@ void g16_launch_final(const G16View& V, const uint32_t* sum_g1, const uint32_t* 
     k_g16_final<<<dim3((V.rows + TW - 1) / TW, 3), TW, 0, st>>>(V, sum_g1, sum_g2, tmp_g1);
 }
 void g16_launch_mimc(const uint64_t* values, uint32_t n, const uint32_t* mimc_c, uint8_t* out, hipStream_t st) { k_mimc_commit<<<(n + TW - 1) / TW, TW, 0, st>>>(values, n, mimc_c, out); }
-// msm_form: the table feeds k_msm_gather (entries on nine 29-bit limbs); false = plain Fq limbs (the verifier's gamma_abc_g1
-// tables, g16_verify.h)
-void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uint32_t* table, hipStream_t st, bool msm_form) {
-    const uint32_t threads = nslots * G16_NWIN;
-    if (!g2) k_g16_build_table<fq, 20><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table, msm_form && G16_WBITS > 10 ? 1u : 0u);
-    else k_g16_build_table<fq2, 40><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table, msm_form && G16_WBITS > 10 ? 1u : 0u);
+// msm_form: the table feeds k_msm_gather (packed nine-limb entries); false = plain Fq limbs (the verifier's gamma_abc_g1 tables,
+// g16_verify.h)
+void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uint32_t* table, hipStream_t st, bool msm_form, const G16Radix& rx) {
+    const uint32_t seg_len = rx.nent < G16_TABLE_SEG ? rx.nent : G16_TABLE_SEG;
+    const uint32_t threads = nslots * rx.nwin * (rx.nent / seg_len);
+    if (!g2) k_g16_build_table<fq, 20><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table, msm_form ? 1u : 0u, rx);
+    else k_g16_build_table<fq2, 40><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table, msm_form ? 1u : 0u, rx);
 }
-// > 64 KB of dynamic LDS needs the opt-in attribute; once per HIP device (called when a shard creates its Groth16 state)
-hipError_t g16_prepare_device() {
-    if constexpr (G16_WBITS > 10) return hipSuccess;           // the gather kernel uses no LDS
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<G1Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<G1Msm>());
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<G2Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<G2Msm>());
-}
-uint32_t g16_table_entry_words(bool g2, bool msm_form) {
-    return (msm_form && G16_WBITS > 10) ? (g2 ? G2Msm::GATHER_W : G1Msm::GATHER_W) : (g2 ? G2Msm::AFF_W : G1Msm::AFF_W);
-}
-uint32_t g16_msm_rows_per_block(bool g2) { return G16_WBITS > 10 ? 256u : (g2 ? G2Msm::TB : G1Msm::TB); }
-uint32_t g16_msm_blocks_per_cu(bool g2) { return G16_WBITS > 10 ? (g2 ? G2Msm::GATHER_WAVES : G1Msm::GATHER_WAVES) : 1u; }
-void g16_launch_msm(bool g2, const MsmView& m, hipStream_t st) {
-    const uint32_t tb = g16_msm_rows_per_block(g2);
-    const uint32_t ngroups = (m.rows + tb - 1) / tb, nblocks = m.nchunks * ngroups, grid = ((nblocks + 7) / 8) * 8;
-    if constexpr (G16_WBITS > 10) {          // HBM-resident radix-2^14 tables, per-lane gathers
-        if (!g2) k_msm_gather<G1Msm><<<grid, 256, 0, st>>>(m, ngroups, nblocks);
-        else k_msm_gather<G2Msm><<<grid, 256, 0, st>>>(m, ngroups, nblocks);
-    } else {                                 // radix-1024 sub-tables streamed through LDS (A/B build)
-        if (!g2) k_msm_dma<G1Msm><<<grid, G1Msm::TB, msm_lds_bytes<G1Msm>(), st>>>(m, ngroups, nblocks);
-        else k_msm_dma<G2Msm><<<grid, G2Msm::TB, msm_lds_bytes<G2Msm>(), st>>>(m, ngroups, nblocks);
-    }
+uint32_t g16_table_entry_words(bool g2, bool msm_form) { return msm_form ? (g2 ? G2Msm::GATHER_W : G1Msm::GATHER_W) : (g2 ? 40u : 20u); }
+uint32_t g16_msm_rows_per_block(bool) { return 256u; }
+uint32_t g16_msm_blocks_per_cu(bool g2) { return g2 ? G2Msm::GATHER_WAVES : G1Msm::GATHER_WAVES; }
+void g16_launch_msm(bool g2, const MsmView& m, hipStream_t st) {      // HBM-resident tables, per-lane gathers; m.nwin / nent / digw = the key's radix
+    const uint32_t ngroups = (m.rows + 255u) / 256u, nblocks = m.nchunks * ngroups, grid = ((nblocks + 7) / 8) * 8;
+    if (!g2) k_msm_gather<G1Msm><<<grid, 256, 0, st>>>(m, ngroups, nblocks);
+    else k_msm_gather<G2Msm><<<grid, 256, 0, st>>>(m, ngroups, nblocks);
 }
 void g16_launch_sum(bool g2, const ReduceView& R, uint32_t* sums, hipStream_t st) {
     const dim3 grid((R.rows + G16_SUM_ROWS - 1) / G16_SUM_ROWS, R.ntargets);

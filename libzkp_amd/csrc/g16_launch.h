@@ -11,9 +11,8 @@ hipError_t g16_launch_qap(const zkp::G16View& V, const zkp::G16Circuit& C, hipSt
 void g16_launch_cparts(const zkp::G16View& V, const uint32_t* sum_g1, uint32_t* tmp_g1, hipStream_t st);
 void g16_launch_final(const zkp::G16View& V, const uint32_t* sum_g1, const uint32_t* sum_g2, const uint32_t* tmp_g1, hipStream_t st);
 void g16_launch_mimc(const uint64_t* values, uint32_t n, const uint32_t* mimc_c, uint8_t* out, hipStream_t st);
-void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uint32_t* table, hipStream_t st, bool msm_form = true);
+void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uint32_t* table, hipStream_t st, bool msm_form, const zkp::G16Radix& rx);
 uint32_t g16_table_entry_words(bool g2, bool msm_form);      // 32-bit words per stored table entry (packed 16 / 32 in the MSM form, 20 / 40 plain)
-hipError_t g16_prepare_device();
 uint32_t g16_msm_rows_per_block(bool g2);      // lanes (= proofs) per MSM workgroup and resident workgroups per CU of the built kernel
 uint32_t g16_msm_blocks_per_cu(bool g2);
 void g16_launch_msm(bool g2, const zkp::MsmView& m, hipStream_t st);

@@ -14,20 +14,37 @@
 
 namespace zkp {
 
-// Key-point tables: signed radix-2^14 digits (two 16-bit digits per word), 19 windows of 8192 affine entries per key point,
-// resident in HBM (~80 GB for the two circuits) and gathered per lane (k_msm_gather): 19 mixed additions per 254-bit scalar
-// where the LDS-streamed radix-1024 tables of round 1 needed 26.  A 64-bit value needs 5 windows, a bit 1.  Measured on the
-// 4096-op mixed batch: radix 2^13 (20 windows, 42 GB) 16.0 ms, 2^14 15.6 ms, 2^15 (17 windows, 143 GB, does not leave room
-// for two shards on one test GPU) another ~1.5 %.  (ZKP_G16_WBITS=10 rebuilds the radix-1024 layout: 26 windows
-// of 512 entries, streamed through LDS by k_msm_dma -- kept for A/B measurements; 13 / 15 build the other HBM layouts.)
+// Key-point tables: signed radix-2^w digits (two 16-bit digits per word), ceil(255 / w) windows of 2^(w-1) affine entries per key
+// point, resident in HBM and gathered per lane (k_msm_gather).  The radix is a property of a LOADED KEY, chosen when the key is
+// installed from the memory the GPU has free (g16_impl.inc: 2^14 when both circuits' ~65 GB fit -- 19 mixed additions per 254-bit
+// scalar, 5 per 64-bit value -- then 2^13, 2^12, ... down to 2^8, 33 MB per circuit); ZKP_HIP_G16_WBITS forces one.  Measured on the
+// 4096-op mixed batch in round 2: radix 2^13 16.0 ms, 2^14 15.6 ms, 2^15 another ~1.5 % for 143 GB; the LDS-streamed radix-1024
+// tables of round 1 needed 26 additions per scalar.
 #ifndef ZKP_G16_WBITS
 #define ZKP_G16_WBITS 14
 #endif
-constexpr uint32_t G16_WBITS = ZKP_G16_WBITS, G16_NWIN = (254 + G16_WBITS) / G16_WBITS, G16_NENT = 1u << (G16_WBITS - 1),
-                   G16_DIGW = (G16_NWIN + 1) / 2, G16_NWIN_U64 = (64 + G16_WBITS) / G16_WBITS;
-static_assert(G16_NWIN * G16_WBITS >= 255 && G16_NWIN_U64 * G16_WBITS >= 65, "windows must cover the scalar and the recoding carry");
-ZKP_HD inline void g16_recode(uint32_t* packed, const sc& raw) { sc_recode_signed<(int)G16_WBITS, (int)G16_NWIN>(packed, raw); }
-
+struct G16Radix { uint32_t wbits, nwin, nent, digw, nwin_u64; };
+ZKP_HD inline G16Radix g16_radix(uint32_t wbits) {
+    G16Radix r; r.wbits = wbits; r.nwin = (254 + wbits) / wbits; r.nent = 1u << (wbits - 1); r.digw = (r.nwin + 1) / 2; r.nwin_u64 = (64 + wbits) / wbits;
+    return r;                           // nwin * wbits >= 255 and nwin_u64 * wbits >= 65: the windows cover the scalar and the recoding carry
+}
+constexpr uint32_t G16_WBITS_DEFAULT = ZKP_G16_WBITS, G16_WBITS_MIN = 8, G16_WBITS_MAX = 15, G16_DIGW_MAX = 16;      // radix 2^8: 32 windows = 16 digit words
+static_assert(G16_WBITS_DEFAULT >= G16_WBITS_MIN && G16_WBITS_DEFAULT <= G16_WBITS_MAX, "key-table radix out of range");
+// packed signed digits of a raw canonical scalar at radix 2^wbits (packed[] holds G16_DIGW_MAX words; the first rx.digw are meaningful)
+ZKP_HD inline void g16_recode(uint32_t* packed, const sc& raw, uint32_t wbits) {
+    switch (wbits) {
+        case 8: sc_recode_signed<8, 32>(packed, raw); break;
+        case 9: sc_recode_signed<9, 29>(packed, raw); break;
+        case 10: sc_recode_signed<10, 26>(packed, raw); break;
+        case 11: sc_recode_signed<11, 24>(packed, raw); break;
+        case 12: sc_recode_signed<12, 22>(packed, raw); break;
+        case 13: sc_recode_signed<13, 20>(packed, raw); break;
+        case 14: sc_recode_signed<14, 19>(packed, raw); break;
+        default: sc_recode_signed<15, 17>(packed, raw); break;
+    }
+}
+// the verifier's public-input tables (gamma_abc_g1: a hundred-odd points, 64-bit scalars mostly) keep a fixed small radix
+constexpr uint32_t G16V_WBITS = 10, G16V_NWIN = 26, G16V_NENT = 512, G16V_NWIN_U64 = 7;
 
 constexpr uint32_t MIMC_ROUNDS = 110, G16_MAX_SET = 64;
 constexpr uint32_t G16_TAPE_IDX = 0x47313600u;
@@ -47,15 +64,16 @@ ZKP_HD inline void g16_put_bytes(uint8_t* dst, const uint32_t* w, int nwords) {
     for (int i = 0; i < nwords; i++) { dst[4 * i] = (uint8_t)w[i]; dst[4 * i + 1] = (uint8_t)(w[i] >> 8); dst[4 * i + 2] = (uint8_t)(w[i] >> 16); dst[4 * i + 3] = (uint8_t)(w[i] >> 24); }
 }
 // packed signed digits of a Montgomery-form Fr element (canonical value < r < 2^254)
-ZKP_HD inline void st_fr_digits(uint32_t* d, uint32_t idx, uint32_t row, uint32_t rows, const fr& x) {
+ZKP_HD inline void st_fr_digits(uint32_t* d, uint32_t idx, uint32_t row, uint32_t rows, const fr& x, const G16Radix& rx) {
     sc raw; fp_to_raw(raw.v, x);
-    uint32_t pk[G16_DIGW]; g16_recode(pk, raw);
-    uint32_t* q = d + (size_t)idx * G16_DIGW * rows + row;
-    ZKP_UNROLL for (uint32_t k = 0; k < G16_DIGW; k++) q[(size_t)k * rows] = pk[k];
+    uint32_t pk[G16_DIGW_MAX]; g16_recode(pk, raw, rx.wbits);
+    uint32_t* q = d + (size_t)idx * rx.digw * rows + row;
+    ZKP_UNROLL for (uint32_t k = 0; k < G16_DIGW_MAX; k++) if (k < rx.digw) q[(size_t)k * rows] = pk[k];
 }
 
 struct G16View {
     uint32_t rows, kind;
+    G16Radix rx;                              // radix of the loaded key's tables = of every digit row below
     uint32_t n_inst, n_wit, nv, m;            // circuit shape; m = domain size
     // inputs
     const uint64_t* value;                    // [rows] the committed value (a for equality, value for membership)
@@ -65,7 +83,7 @@ struct G16View {
     const uint32_t* mimc_c;                   // [110][8] round constants (Montgomery Fr)
     // workspace
     uint32_t* z;                              // [nv][8][rows] full assignment (instance block first), Montgomery Fr
-    uint32_t* sdig;                           // [nscalars][G16_DIGW][rows] packed digits: z_k (nv), h_i (m-1), r, s, -rs, one
+    uint32_t* sdig;                           // [nscalars][rx.digw][rows] packed digits: z_k (nv), h_i (m-1), r, s, -rs, one
     uint32_t* rs;                             // [2][8][rows] raw canonical r, s (for the variable-base part of C)
     // output
     uint8_t* out; uint64_t stride;            // envelope per row
@@ -140,17 +158,17 @@ ZKP_HD inline void step_g16_witness(const G16View& V, uint32_t row) {
     uint32_t w[16];
     tape_draw64(w, seed, G16_TAPE_IDX, 0); const fr r = fp_from_wide<FrParams>(w);
     tape_draw64(w, seed, G16_TAPE_IDX, 1); const fr s = fp_from_wide<FrParams>(w);
-    st_fr_digits(V.sdig, g16_sc_r(V), row, rows, r);
-    st_fr_digits(V.sdig, g16_sc_s(V), row, rows, s);
-    st_fr_digits(V.sdig, g16_sc_nrs(V), row, rows, fp_neg(fp_mul(r, s)));
-    uint32_t* q = V.sdig + (size_t)g16_sc_one(V) * G16_DIGW * rows + row;
-    q[0] = 1u; for (uint32_t k = 1; k < G16_DIGW; k++) q[(size_t)k * rows] = 0u;
+    st_fr_digits(V.sdig, g16_sc_r(V), row, rows, r, V.rx);
+    st_fr_digits(V.sdig, g16_sc_s(V), row, rows, s, V.rx);
+    st_fr_digits(V.sdig, g16_sc_nrs(V), row, rows, fp_neg(fp_mul(r, s)), V.rx);
+    uint32_t* q = V.sdig + (size_t)g16_sc_one(V) * V.rx.digw * rows + row;
+    q[0] = 1u; for (uint32_t k = 1; k < V.rx.digw; k++) q[(size_t)k * rows] = 0u;
     fr rr, sr; fp_to_raw(rr.v, r); fp_to_raw(sr.v, s);
     st_fr(V.rs, 0, row, rows, rr); st_fr(V.rs, 1, row, rows, sr);
 }
 // thread = (variable k, proof): digits of z_k
 ZKP_HD inline void step_g16_zdigits(const G16View& V, uint32_t k, uint32_t row) {
-    st_fr_digits(V.sdig, k, row, V.rows, ld_fr(V.z, k, row, V.rows));
+    st_fr_digits(V.sdig, k, row, V.rows, ld_fr(V.z, k, row, V.rows), V.rx);
 }
 
 // ---- R1CS matrices in CSR form (coefficients in Montgomery Fr) and the domain tables, all read-only
@@ -231,7 +249,7 @@ ZKP_HD inline void g16_pointwise(const G16Circuit& C, const G16Lds& L, uint32_t 
 }
 ZKP_HD inline void g16_store_h(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t row, uint32_t tid, uint32_t nthreads) {
     for (uint32_t i = tid; i + 1 < C.m; i += nthreads)
-        st_fr_digits(V.sdig, g16_sc_h(V) + i, row, V.rows, fr9_to_fr<FrParams>(fr9_mul(L.ld(0, i), ld_fr9_c(C.coset_inv, i))));
+        st_fr_digits(V.sdig, g16_sc_h(V) + i, row, V.rows, fr9_to_fr<FrParams>(fr9_mul(L.ld(0, i), ld_fr9_c(C.coset_inv, i))), V.rx);
 }
 // the whole witness map, written so that host emulation (nthreads = 1, sync = no-op) and the kernel share it
 template <class Sync>

@@ -16,7 +16,7 @@ struct G16Vk {
     fq12 ml_alpha_beta;            // Miller loop value of (beta, -alpha): the constant factor of the check
     uint32_t n_ic;                 // gamma_abc_g1 length (1 + public inputs)
     const uint32_t* ic;            // [n_ic][20] affine points, Montgomery limbs
-    const uint32_t* ic_table;      // optional [n_ic][G16_NWIN windows][G16_NENT entries][20]: entry e of window w = (e + 1) * 2^(WBITS w) * IC_i (affine)
+    const uint32_t* ic_table;      // optional [n_ic][G16V_NWIN windows][G16V_NENT entries][20]: entry e of window w = (e + 1) * 2^(WBITS w) * IC_i (affine)
 };
 
 ZKP_HD inline uint32_t ld_u32_le(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -88,14 +88,14 @@ ZKP_HD_NOINLINE inline g1_jac g16_ic_mul(const G16Vk& vk, uint32_t i, const uint
     g1_jac acc = jac_infinity<fq>();
     uint32_t carry = 0;
     for (uint32_t w = 0; w < nwin; w++) {
-        const uint32_t bit = G16_WBITS * w, wd = bit >> 5, sh = bit & 31u;
+        const uint32_t bit = G16V_WBITS * w, wd = bit >> 5, sh = bit & 31u;
         uint32_t x = wd < 8 ? k[wd] >> sh : 0u;
-        if (sh + G16_WBITS > 32 && wd + 1 < 8) x |= k[wd + 1] << (32 - sh);
-        const uint32_t dd = (x & ((1u << G16_WBITS) - 1u)) + carry;            // 0 .. 2^WBITS
-        carry = dd > G16_NENT ? 1u : 0u;
-        const int32_t d = (int32_t)dd - (int32_t)(carry << G16_WBITS);         // [-(NENT - 1), NENT]
+        if (sh + G16V_WBITS > 32 && wd + 1 < 8) x |= k[wd + 1] << (32 - sh);
+        const uint32_t dd = (x & ((1u << G16V_WBITS) - 1u)) + carry;            // 0 .. 2^WBITS
+        carry = dd > G16V_NENT ? 1u : 0u;
+        const int32_t d = (int32_t)dd - (int32_t)(carry << G16V_WBITS);         // [-(NENT - 1), NENT]
         if (d == 0) continue;
-        const uint32_t* e = vk.ic_table + (((size_t)i * G16_NWIN + w) * G16_NENT + (uint32_t)((d < 0 ? -d : d) - 1)) * 20;
+        const uint32_t* e = vk.ic_table + (((size_t)i * G16V_NWIN + w) * G16V_NENT + (uint32_t)((d < 0 ? -d : d) - 1)) * 20;
         g1_aff q; for (int j = 0; j < 10; j++) { q.x.v[j] = e[j]; q.y.v[j] = e[10 + j]; }
         if (d < 0) q.y = fq_neg(q.y);
         acc = jac_madd(acc, q);
@@ -131,7 +131,7 @@ ZKP_HD_NOINLINE inline bool g16_equality_pairs(const G16Vk& vk, const uint8_t* e
     if (ld_u32_le(env + 2) != 256 || ld_u32_le(env + 6) != 32) return false;
     uint32_t c[8]; ld_le_words(c, env + 266);
     if (!fr_raw_lt_r(c)) return false;
-    const g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), g16_ic_mul(vk, 1, c, G16_NWIN));
+    const g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), g16_ic_mul(vk, 1, c, G16V_NWIN));
     return g16_pairs(vk, env + 10, L, o);
 }
 // membership envelope (scheme 4): payload = u32 n || n x u64 set || 256-byte proof; public inputs =
@@ -145,11 +145,11 @@ ZKP_HD_NOINLINE inline bool g16_membership_pairs(const G16Vk& vk, const uint8_t*
     if (n > G16_MAX_SET || plen != 4 + 8 * n + 256) return false;
     uint32_t c[8]; ld_le_words(c, env + 10 + plen);
     if (!fr_raw_lt_r(c)) return false;
-    g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), g16_ic_mul(vk, 1, c, G16_NWIN));
+    g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), g16_ic_mul(vk, 1, c, G16V_NWIN));
     for (uint32_t i = 0; i < n; i++) {
         uint64_t v = 0; for (int k = 0; k < 8; k++) v |= (uint64_t)env[14 + 8 * i + k] << (8 * k);
         const uint32_t vw[8] = {(uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0};
-        if (v) L = jac_add(L, vk.ic_table ? g16_ic_mul(vk, 2 + i, vw, G16_NWIN_U64) : g1_mul_u64(ld_ic(vk, 2 + i), v));
+        if (v) L = jac_add(L, vk.ic_table ? g16_ic_mul(vk, 2 + i, vw, G16V_NWIN_U64) : g1_mul_u64(ld_ic(vk, 2 + i), v));
         L = jac_madd(L, ld_ic(vk, 2 + G16_MAX_SET + i));            // is_real = 1
     }
     return g16_pairs(vk, env + 14 + 8 * n, L, o);

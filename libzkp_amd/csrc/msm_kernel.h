@@ -79,7 +79,8 @@ __global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint
 }
 
 // ---- HBM-resident tables, per-lane gathers (Groth16 key points).  The tables are sized for HBM, not for LDS: radix 2^14
-// needs 8192 entries per (key point, window) -- 512 KB for G1, 1 MB for G2, tens of GB per key in total -- so each lane
+// needs 8192 entries per (key point, window) -- 512 KB for G1, 1 MB for G2, tens of GB per key in total; the shape (m.nwin, m.nent,
+// m.digw) is a run-time property of the loaded key, smaller radices for GPUs with less free memory -- so each lane
 // fetches the one entry its digit selects straight from global memory (the workgroups that share a chunk sit on one XCD and
 // walk the same sub-tables at the same time, so a good part of the entries is served from that XCD's L2).  No LDS, no
 // barrier: a workgroup is four independent waves.  Loads are software-pipelined when the point type has the registers for it
@@ -100,11 +101,11 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
     const uint4* const table4 = reinterpret_cast<const uint4*>(m.table);
     auto digit_word = [&](uint32_t slot, uint32_t win) -> uint32_t {
         const uint32_t srow = m.slot_scalar ? m.slot_scalar[slot] : slot;
-        return active ? m.digits[((size_t)srow * T::DIGW + win / T::DIG_PER_WORD) * m.rows + row] : 0u;
+        return active ? m.digits[((size_t)srow * m.digw + win / T::DIG_PER_WORD) * m.rows + row] : 0u;
     };
     auto fetch = [&](uint4* e, uint32_t slot, uint32_t win, int32_t d) {
         if (d == 0) return;
-        const uint4* src = table4 + (((size_t)m.slot_base[slot] * T::NWIN + win) * T::NENT + (uint32_t)((d < 0 ? -d : d) - 1)) * V4;
+        const uint4* src = table4 + (((size_t)m.slot_base[slot] * m.nwin + win) * m.nent + (uint32_t)((d < 0 ? -d : d) - 1)) * V4;
         ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) e[k] = src[k];
     };
     if (left == 0) { if (active) T::store(m.partial, chunk, row, m.rows, T::from_gather(acc)); return; }

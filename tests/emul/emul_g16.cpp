@@ -11,16 +11,17 @@ extern "C" {
 // kind 0 equality / 1 membership.  Outputs: z_raw [nv][8] canonical words, h_raw [m-1][8], envelope prefix bytes.
 // h is returned through its signed digits (what the MSM consumes), re-assembled to the canonical value.
 int emul_g16_witness_qap(int kind, uint64_t value, const uint64_t* set_vals, uint32_t set_len, const uint8_t seed[32],
-                         uint32_t* z_raw, uint32_t* h_raw, uint32_t* rs_raw, uint8_t* out, uint64_t stride, uint32_t* shape) {
+                         uint32_t* z_raw, uint32_t* h_raw, uint32_t* rs_raw, uint8_t* out, uint64_t stride, uint32_t* shape, uint32_t radix_bits) {
     const HostR1CS cs = kind == 0 ? build_equality_r1cs() : build_membership_r1cs();
     const HostCircuitTables T = build_circuit_tables(cs);
     ensure_mimc_constants();
     std::vector<uint32_t> mc; for (auto& c : g_mimc_host) put_fr(mc, c);
     const uint32_t nsc = g16_nscalars(T.nv, T.m);
-    std::vector<uint32_t> z((size_t)T.nv * 8), sdig((size_t)nsc * G16_DIGW), rs(16), seedw(8);
+    const G16Radix rx = g16_radix(radix_bits ? radix_bits : G16_WBITS_DEFAULT);
+    std::vector<uint32_t> z((size_t)T.nv * 8), sdig((size_t)nsc * rx.digw), rs(16), seedw(8);
     memcpy(seedw.data(), seed, 32);
     uint64_t sv[G16_MAX_SET] = {0}; for (uint32_t i = 0; i < set_len && i < G16_MAX_SET; i++) sv[i] = set_vals[i];
-    G16View V{}; V.rows = 1; V.kind = (uint32_t)kind; V.n_inst = T.n_inst; V.n_wit = T.n_wit; V.nv = T.nv; V.m = T.m;
+    G16View V{}; V.rx = rx; V.rows = 1; V.kind = (uint32_t)kind; V.n_inst = T.n_inst; V.n_wit = T.n_wit; V.nv = T.nv; V.m = T.m;
     V.value = &value; V.set_vals = sv; V.set_len = &set_len; V.seeds = seedw.data(); V.mimc_c = mc.data();
     V.z = z.data(); V.sdig = sdig.data(); V.rs = rs.data(); V.out = out; V.stride = stride;
     step_g16_witness(V, 0);
@@ -38,9 +39,9 @@ int emul_g16_witness_qap(int kind, uint64_t value, const uint64_t* set_vals, uin
     auto undigit = [&](uint32_t idx, uint32_t* outw) {
         unsigned __int128 lo = 0, hi = 0;     // 260-bit accumulator as two halves: value = hi * 2^128 + lo (two's complement overall)
         // Horner from the top digit: acc = acc * 2^WBITS + d
-        for (int j = (int)G16_NWIN - 1; j >= 0; j--) {
-            const int32_t d = (int32_t)(int16_t)(sdig[(size_t)idx * G16_DIGW + (j >> 1)] >> (16 * (j & 1)));
-            hi = (hi << G16_WBITS) | (lo >> (128 - G16_WBITS)); lo <<= G16_WBITS;
+        for (int j = (int)rx.nwin - 1; j >= 0; j--) {
+            const int32_t d = (int32_t)(int16_t)(sdig[(size_t)idx * rx.digw + (j >> 1)] >> (16 * (j & 1)));
+            hi = (hi << rx.wbits) | (lo >> (128 - rx.wbits)); lo <<= rx.wbits;
             if (d >= 0) { const unsigned __int128 t = lo + (unsigned)d; if (t < lo) hi++; lo = t; }
             else { const unsigned __int128 t = lo - (unsigned)(-d); if (t > lo) hi--; lo = t; }
         }
@@ -64,12 +65,12 @@ int emul_g16_verify(int kind, const uint8_t* env, uint32_t len, const uint32_t* 
     // small keys (equality: two points) also get the window tables the GPU path uses, built as k_g16_build_table builds them
     std::vector<uint32_t> tab;
     if (n_ic <= 2) {
-        tab.resize((size_t)n_ic * G16_NWIN * G16_NENT * 20);
+        tab.resize((size_t)n_ic * G16V_NWIN * G16V_NENT * 20);
         for (uint32_t i = 0; i < n_ic; i++) {
             g1_jac q = jac_from_aff(g1(ic + 16 * i));
-            for (uint32_t w = 0; w < G16_NWIN; w++) {
+            for (uint32_t w = 0; w < G16V_NWIN; w++) {
                 g1_jac acc = q;
-                for (uint32_t e0 = 0; e0 < G16_NENT; e0 += 8) {          // the device builder's batched conversion (k_g16_build_table)
+                for (uint32_t e0 = 0; e0 < G16V_NENT; e0 += 8) {          // the device builder's batched conversion (k_g16_build_table)
                     g1_jac pts[8]; fq zp[8];
                     for (uint32_t k = 0; k < 8; k++) { pts[k] = acc; acc = jac_add(acc, q); zp[k] = k ? f_mul(zp[k - 1], pts[k].Z) : pts[k].Z; }
                     fq inv = f_inv(zp[7]);
@@ -78,11 +79,11 @@ int emul_g16_verify(int kind, const uint8_t* env, uint32_t len, const uint32_t* 
                         if (k) inv = f_mul(inv, pts[k].Z);
                         const fq zi2 = f_sq(zi);
                         g1_aff a; a.x = f_mul(pts[k].X, zi2); a.y = f_mul(pts[k].Y, f_mul(zi2, zi));
-                        uint32_t* dst = tab.data() + (((size_t)i * G16_NWIN + w) * G16_NENT + e0 + k) * 20;
+                        uint32_t* dst = tab.data() + (((size_t)i * G16V_NWIN + w) * G16V_NENT + e0 + k) * 20;
                         for (int j = 0; j < 10; j++) { dst[j] = a.x.v[j]; dst[10 + j] = a.y.v[j]; }
                     }
                 }
-                for (uint32_t k = 0; k < G16_WBITS; k++) q = jac_dbl(q);
+                for (uint32_t k = 0; k < G16V_WBITS; k++) q = jac_dbl(q);
             }
         }
         vk.ic_table = tab.data();

@@ -177,7 +177,7 @@ def test_key_table_entries_pack_into_eight_words(libs):
         assert I(packed) == v
 
 
-def _run(lib, kind, value, the_set, seed):
+def _run(lib, kind, value, the_set, seed, radix_bits=0):
     nv, m = (334, 512) if kind == 0 else (653, 1024)
     z = np.zeros((nv, 8), dtype=np.uint32)
     h = np.zeros((m - 1, 8), dtype=np.uint32)
@@ -186,7 +186,7 @@ def _run(lib, kind, value, the_set, seed):
     shape = np.zeros(4, dtype=np.uint32)
     sv = np.array(list(the_set) + [0], dtype=np.uint64)
     P = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
-    lib.emul_g16_witness_qap(kind, ctypes.c_uint64(value), P(sv), len(the_set), seed, P(z), P(h), P(rs), P(out), ctypes.c_uint64(1024), P(shape))
+    lib.emul_g16_witness_qap(kind, ctypes.c_uint64(value), P(sv), len(the_set), seed, P(z), P(h), P(rs), P(out), ctypes.c_uint64(1024), P(shape), radix_bits)
     toint = lambda a: [int.from_bytes(r.tobytes(), "little") for r in a]  # noqa: E731
     return toint(z), toint(h), toint(rs.reshape(2, 8)), out.tobytes(), [int(x) for x in shape]
 
@@ -210,6 +210,17 @@ def test_witness_and_quotient_equal_oracle(libs):
         n = len(the_set)
         assert out[:2] == bytes([2, 4]) and out[10:14] == n.to_bytes(4, "little")
         assert out[14:14 + 8 * n] == b"".join(x.to_bytes(8, "little") for x in the_set)
+
+
+def test_digit_rows_at_every_key_table_radix(libs):
+    """The radix of a key's tables is chosen when the key is loaded (2^14 down to 2^8 by free memory): the witness / QAP steps write
+    their digit rows for whatever radix the view carries, and the digits of every radix reassemble to the same h."""
+    _, lib = libs
+    seed = bytes(range(32))
+    want = _run(lib, 0, 42, [], seed)
+    for wb in (8, 9, 10, 11, 12, 13, 15):
+        got = _run(lib, 0, 42, [], seed, wb)
+        assert got == want, wb
 
 
 def _vk_args(pk):

@@ -191,3 +191,78 @@ def test_python_api_snark(hip, monkeypatch):
     assert g.verify_membership(proofs[3], [3, 7, 9], SS)
     r = z.benchmark_proof_generation("equality", 2)
     assert r["proof_type"] == "equality" and float(r["success_rate"]) == 100.0
+
+
+def _prove_some(L):
+    """64 equality + 32 membership proofs with fixed seeds through the per-variant entry points; returns the bytes."""
+    from libzkp_amd import workloads as wl
+    from util import P
+    n = 64
+    rng = np.random.default_rng(77)
+    a = rng.integers(0, 2**64, n, dtype=np.uint64)
+    sd = wl.op_seeds(78, n)
+    o = np.zeros((n, 298), dtype=np.uint8); ln = np.zeros(n, dtype=np.uint32); st = np.zeros(n, dtype=np.int32)
+    assert L.zkp_hip_prove_equality_batch(n, P(a), P(a), P(sd), P(o), 298, P(ln), P(st)) == 0 and not st.any()
+    m = 32
+    sets = np.stack([rng.choice(2**32, 16, replace=False) for _ in range(m)]).astype(np.uint64)
+    vals = sets[np.arange(m), np.arange(m) % 16].copy()
+    cnt = np.full(m, 16, dtype=np.uint32)
+    stride = 10 + 4 + 8 * 16 + 256 + 32
+    o2 = np.zeros((m, stride), dtype=np.uint8); l2 = np.zeros(m, dtype=np.uint32); s2 = np.zeros(m, dtype=np.int32)
+    flat = np.ascontiguousarray(sets.ravel())
+    assert L.zkp_hip_prove_membership_batch(m, P(vals), P(flat), P(cnt), P(sd[:32 * m].copy()), P(o2), stride, P(l2), P(s2)) == 0 and not s2.any()
+    return o.tobytes() + o2.tobytes()
+
+
+def test_key_tables_are_sized_at_load_time_and_the_bytes_do_not_change():
+    """The radix of a key's window tables is chosen when the key is loaded, from the memory budget (snark.rs:40-70,122-139 loads a 140 KB
+    key into any process): with ~1.2 GB per key the equality key falls back from radix 2^14 to 2^9 and the membership key to 2^8, the
+    proofs stay bit-identical; with a budget nothing fits into, the load fails with a message that says so."""
+    from libzkp_amd import _native
+    L = _native.lib()
+    _native.check(L.zkp_hip_init(0), "zkp_hip_init")
+    keys = [(kind, open(os.path.join(GOLD, name), "rb").read()) for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin"))]
+    def load():
+        return [L.zkp_hip_groth16_load_key(kind, blob, len(blob)) for kind, blob in keys]
+    assert load() == [0, 0], _native.last_error()
+    want = _prove_some(L)
+    try:
+        os.environ["ZKP_HIP_G16_TABLE_BUDGET_MB"] = "1200"
+        assert load() == [0, 0], _native.last_error()
+        assert _prove_some(L) == want
+        for wb in ("11", "13"):
+            os.environ["ZKP_HIP_G16_WBITS"] = wb
+            assert load() == [0, 0], _native.last_error()
+            assert _prove_some(L) == want, wb
+        del os.environ["ZKP_HIP_G16_WBITS"]
+        os.environ["ZKP_HIP_G16_TABLE_BUDGET_MB"] = "100"
+        assert load()[0] < 0 and "not enough device memory" in _native.last_error()
+    finally:
+        os.environ.pop("ZKP_HIP_G16_TABLE_BUDGET_MB", None); os.environ.pop("ZKP_HIP_G16_WBITS", None)
+        assert load() == [0, 0], _native.last_error()
+    assert _prove_some(L) == want
+
+
+def test_shards_of_one_gpu_share_a_key_s_tables():
+    import torch
+    from libzkp_amd import _native
+    L = _native.lib()
+    keys = [(kind, open(os.path.join(GOLD, name), "rb").read()) for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin"))]
+    L.zkp_hip_shutdown()
+    try:
+        _native.init_devices([0])
+        for kind, blob in keys:
+            assert L.zkp_hip_groth16_load_key(kind, blob, len(blob)) == 0, _native.last_error()
+        free1 = torch.cuda.mem_get_info(0)[0]
+        L.zkp_hip_shutdown()
+        _native.init_devices([0, 0])
+        for kind, blob in keys:
+            assert L.zkp_hip_groth16_load_key(kind, blob, len(blob)) == 0, _native.last_error()
+        free2 = torch.cuda.mem_get_info(0)[0]
+        assert free1 - free2 < 8 << 30, (free1 >> 20, free2 >> 20)          # a second copy of the tables would be tens of GB
+        assert _prove_some(L)                                               # (shard 0 of the two)
+    finally:
+        L.zkp_hip_shutdown()
+        _native.check(L.zkp_hip_init(0), "zkp_hip_init")
+        for kind, blob in keys:
+            assert L.zkp_hip_groth16_load_key(kind, blob, len(blob)) == 0
