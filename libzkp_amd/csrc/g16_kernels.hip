@@ -63,7 +63,7 @@ struct DevSync { __device__ __forceinline__ void operator()() const { __syncthre
 // 512 lanes: the 108 KB LDS image of a membership proof allows one workgroup per CU, so the workgroup itself has to bring the
 // waves (2 per SIMD) that hide the LDS latency of the butterfly stages
 static constexpr int QAP_TB = 512;
-__global__ void __launch_bounds__(QAP_TB, ZKP_LAT_WAVES) k_g16_qap(G16View V, G16Circuit C) {
+__global__ void __launch_bounds__(QAP_TB) k_g16_qap(G16View V, G16Circuit C) {
     extern __shared__ uint32_t g16_lds[];
     G16Lds L; L.base = g16_lds; L.m = C.m;
     g16_qap_proof(V, C, L, blockIdx.x, threadIdx.x, QAP_TB, DevSync());

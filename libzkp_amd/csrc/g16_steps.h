@@ -191,15 +191,26 @@ ZKP_HD inline uint32_t g16_bitrev(uint32_t x, uint32_t bits) {
 // The QAP witness map of ONE proof on a word-major image x[poly][word][element] (LDS on the GPU).  `nthreads` lanes
 // cooperate; `sync` is the workgroup barrier.  Reference semantic: LibsnarkReduction::witness_map_from_matrices.
 // the three polynomials of a proof as nine-limb elements (bn254_fr9.h), word-major: 3 x 9 x m words
+// Element e of a word row sits at e ^ (31 if bit 5 of e is set): ds_read_b32 / ds_write_b32 bank a 32-lane half over 32 banks, and the
+// butterfly stages with half < 32 touch e = 2 half g + j (j < half) -- every second run of `half` consecutive words -- so that the lanes
+// of a half-wave with g's top bit set landed on the banks of those with it clear (2-way conflicts in five of the nine / ten stages of
+// each of the seven transforms; round 2 counted more conflict cycles than LDS-active cycles in this kernel).  Inverting the low five
+// address bits for those lanes sends them to exactly the banks the others leave free; for half >= 32 a half-wave reads 32 consecutive
+// words either way.
 struct G16Lds {
     uint32_t* base; uint32_t m;
-    ZKP_HD fr9 ld(uint32_t poly, uint32_t e) const { fr9 r; ZKP_UNROLL for (int k = 0; k < 9; k++) r.v[k] = base[((size_t)poly * 9 + k) * m + e]; return r; }
-    ZKP_HD void st(uint32_t poly, uint32_t e, const fr9& v) const { ZKP_UNROLL for (int k = 0; k < 9; k++) base[((size_t)poly * 9 + k) * m + e] = v.v[k]; }
+    ZKP_HD static uint32_t sw(uint32_t e) { return e ^ ((0u - ((e >> 5) & 1u)) & 31u); }
+    ZKP_HD fr9 ld(uint32_t poly, uint32_t e) const { fr9 r; const uint32_t p = sw(e); ZKP_UNROLL for (int k = 0; k < 9; k++) r.v[k] = base[((size_t)poly * 9 + k) * m + p]; return r; }
+    ZKP_HD void st(uint32_t poly, uint32_t e, const fr9& v) const { const uint32_t p = sw(e); ZKP_UNROLL for (int k = 0; k < 9; k++) base[((size_t)poly * 9 + k) * m + p] = v.v[k]; }
 };
 ZKP_HD inline fr9 ld_fr9_c(const uint32_t* p, uint32_t idx) { fr9 r; ZKP_UNROLL for (int k = 0; k < 9; k++) r.v[k] = p[(size_t)idx * 9 + k]; return r; }
 // phase functions; each is called by every lane `tid` of the workgroup with a barrier between phases
 ZKP_HD inline void g16_qap_load(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t row, uint32_t tid, uint32_t nthreads) {
     const uint32_t nc = C.n_rows;
+    // natural order: lane j evaluates constraint row j (consecutive lanes read consecutive CSR rows; the waves past the last row do
+    // nothing) and stores to position j.  The first transform is therefore decimation-in-frequency (natural in, bit-reversed out); a
+    // decimation-in-time first transform needed its input scattered to bit-reversed positions -- 32 lanes on two banks -- or, with the
+    // rows dealt in bit-reversed order instead, gave every wave a share of the padding rows (equality: 334 of 512 rows are real).
     for (uint32_t j = tid; j < C.m; j += nthreads) {
         fr a = fp_zero<FrParams>(), b = a, c = a;
         if (j < nc) {
@@ -209,8 +220,7 @@ ZKP_HD inline void g16_qap_load(const G16View& V, const G16Circuit& C, const G16
         } else if (j < nc + V.n_inst) {
             a = ld_fr(V.z, j - nc, row, V.rows);                    // a[n_constraints + i] = z_i (instance)
         }
-        const uint32_t p = g16_bitrev(j, C.logm);                   // DIT inverse transform wants bit-reversed input
-        L.st(0, p, fr9_from_fr(a)); L.st(1, p, fr9_from_fr(b)); L.st(2, p, fr9_from_fr(c));      // < 1.4 r each
+        L.st(0, j, fr9_from_fr(a)); L.st(1, j, fr9_from_fr(b)); L.st(2, j, fr9_from_fr(c));      // < 1.4 r each
     }
 }
 // one DIT stage (len = 2*half) on `npoly` polynomials with twiddle table tw (stride m/len)
@@ -236,31 +246,36 @@ ZKP_HD inline void g16_dif_stage(const G16Circuit& C, const G16Lds& L, const uin
         }
     }
 }
-ZKP_HD inline void g16_scale(const G16Circuit& C, const G16Lds& L, const uint32_t* tab, uint32_t npoly, uint32_t tid, uint32_t nthreads) {
-    for (uint32_t i = tid; i < C.m; i += nthreads) {
-        const fr9 f = ld_fr9_c(tab, i);
-        for (uint32_t p = 0; p < npoly; p++) L.st(p, i, fr9_mul(L.ld(p, i), f));
+// element at position p of a bit-reversed image has index bitrev(p): scale it by tab[bitrev(p)]
+ZKP_HD inline void g16_scale_bitrev(const G16Circuit& C, const G16Lds& L, const uint32_t* tab, uint32_t npoly, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t p = tid; p < C.m; p += nthreads) {
+        const fr9 f = ld_fr9_c(tab, g16_bitrev(p, C.logm));
+        for (uint32_t q = 0; q < npoly; q++) L.st(q, p, fr9_mul(L.ld(q, p), f));
     }
 }
 ZKP_HD inline void g16_pointwise(const G16Circuit& C, const G16Lds& L, uint32_t tid, uint32_t nthreads) {
     const fr9 zinv = ld_fr9_c(C.zinv, 0);
-    for (uint32_t i = tid; i < C.m; i += nthreads)
-        L.st(0, i, fr9_mul(fr9_sub_k<4>(fr9_mul(L.ld(0, i), L.ld(1, i)), L.ld(2, i)), zinv));
+    for (uint32_t i = tid; i < C.m; i += nthreads)          // operands are outputs of ten decimation-in-time stages (< 22 r): a b < 3.9 r, c < 32 r
+        L.st(0, i, fr9_mul(fr9_sub_k<32>(fr9_mul(L.ld(0, i), L.ld(1, i)), L.ld(2, i)), zinv));
 }
-ZKP_HD inline void g16_store_h(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t row, uint32_t tid, uint32_t nthreads) {
-    for (uint32_t i = tid; i + 1 < C.m; i += nthreads)
-        st_fr_digits(V.sdig, g16_sc_h(V) + i, row, V.rows, fr9_to_fr<FrParams>(fr9_mul(L.ld(0, i), ld_fr9_c(C.coset_inv, i))), V.rx);
+ZKP_HD inline void g16_store_h_bitrev(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t row, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t p = tid; p < C.m; p += nthreads) {
+        const uint32_t i = g16_bitrev(p, C.logm);             // coefficient index of the element at position p
+        if (i + 1 < C.m) st_fr_digits(V.sdig, g16_sc_h(V) + i, row, V.rows, fr9_to_fr<FrParams>(fr9_mul(L.ld(0, p), ld_fr9_c(C.coset_inv, i))), V.rx);
+    }
 }
-// the whole witness map, written so that host emulation (nthreads = 1, sync = no-op) and the kernel share it
+// the whole witness map, written so that host emulation (nthreads = 1, sync = no-op) and the kernel share it.  Transform order:
+// DIF inverse (natural -> bit-reversed), coset scaling by index, DIT forward (bit-reversed -> natural), pointwise, DIF inverse,
+// coefficients read off by index: no pass of the LDS image is a bit-reversal scatter.
 template <class Sync>
 ZKP_HD inline void g16_qap_proof(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t row, uint32_t tid, uint32_t nthreads, Sync sync) {
     g16_qap_load(V, C, L, row, tid, nthreads); sync();
-    for (uint32_t half = 1; half < C.m; half <<= 1) { g16_dit_stage(C, L, C.tw_inv, half, 3, tid, nthreads); sync(); }   // iFFT (x m)
-    g16_scale(C, L, C.coset, 3, tid, nthreads); sync();                                                                // /m and coset shift g^i
-    for (uint32_t half = C.m / 2; half >= 1; half >>= 1) { g16_dif_stage(C, L, C.tw, half, 3, tid, nthreads); sync(); } // coset FFT (bit-reversed out)
-    g16_pointwise(C, L, tid, nthreads); sync();                                                                        // (a*b - c) / Z(g w^j)
-    for (uint32_t half = 1; half < C.m; half <<= 1) { g16_dit_stage(C, L, C.tw_inv, half, 1, tid, nthreads); sync(); }   // coset iFFT
-    g16_store_h(V, C, L, row, tid, nthreads);                                                                          // /m, g^-i, digits
+    for (uint32_t half = C.m / 2; half >= 1; half >>= 1) { g16_dif_stage(C, L, C.tw_inv, half, 3, tid, nthreads); sync(); }   // iFFT (x m), bit-reversed out
+    g16_scale_bitrev(C, L, C.coset, 3, tid, nthreads); sync();                                                              // /m and coset shift g^i
+    for (uint32_t half = 1; half < C.m; half <<= 1) { g16_dit_stage(C, L, C.tw, half, 3, tid, nthreads); sync(); }            // coset FFT, natural out
+    g16_pointwise(C, L, tid, nthreads); sync();                                                                             // (a*b - c) / Z(g w^j)
+    for (uint32_t half = C.m / 2; half >= 1; half >>= 1) { g16_dif_stage(C, L, C.tw_inv, half, 1, tid, nthreads); sync(); }   // coset iFFT, bit-reversed out
+    g16_store_h_bitrev(V, C, L, row, tid, nthreads);                                                                        // /m, g^-i, digits
 }
 
 // ---- final assembly.  thread = proof.  sums: [4 targets][words][rows] Jacobian sums A (G1), B1 (G1), Cp (G1), B2 (G2)

@@ -17,9 +17,9 @@
 #define ZKP_UNROLL
 #endif
 
-// Register budget of the light chain kernels (k_poly, k_round_prep, k_round_sum, k_poly_sum, k_g16_qap).  In a mixed batch they start
+// Register budget of the light chain kernels (k_poly, k_round_prep, k_round_sum, k_poly_sum).  In a mixed batch they start
 // beside the Groth16 gather kernels, which hold three 136-VGPR waves on every SIMD: 104 of the 512 registers are left, so a kernel
-// compiled for five waves per SIMD (<= 96 VGPRs) is resident the moment its launch is reached.  These five were at 100-106 and give
+// compiled for five waves per SIMD (<= 96 VGPRs) is resident the moment its launch is reached.  These four were at 80-106 and give
 // up 2-15 spilled registers for it.  Tried in round 3 and NOT kept: the same cap on the heavy ones (k_encode 256 -> 96 VGPRs with 211
 // spills, k_sum_t<EdMsm> 351, k_g16_cparts 478, k_g16_final 184, k_g16_witness 55): the mixed batch went from 13.7 to 14.5 ms and
 // equality alone from 4.8 to 5.5 ms -- their time is instruction latency and the scratch round trips add to it; the transcript kernels

@@ -436,7 +436,8 @@ const DevLayout& pick_layout(const LayoutSet& S, uint32_t rows) {
     // workgroups (measured: 1.5 rounds cost 1.30x of 1 round, 2 rounds 1.00x with half-size chunks).  Take the window-
     // granular layout that minimises rounds x (windows per workgroup + per-workgroup overhead) + the partial-sum work
     // that grows with the chunk count; g_fill scales the resident count (benchmarking knob, default 1).
-    const double resident = g_fill * (double)(dev().cus_now ? dev().cus_now : dev().num_cu) * dev().msm_blocks_per_cu;
+    static const int fill_pct = env_int("ZKP_HIP_BP_FILL", 100);      // tuning knob: size the MSM grids for this percentage of the CUs
+    const double resident = g_fill * (fill_pct / 100.0) * (double)(dev().cus_now ? dev().cus_now : dev().num_cu) * dev().msm_blocks_per_cu;
     const uint32_t groups = (rows + EdMsm::TB - 1) / EdMsm::TB;
     size_t best = MAXT; double best_cost = 1e300;
     for (size_t i = MAXT; i < S.cand.size(); i++) {
@@ -507,7 +508,7 @@ int init_device() {
     if ((rc = upload_set(D.ct, targets_ctask()))) return rc;
     D.max_chunks = D.p2.max_chunks;
     if ((rc = ensure_family(6))) return rc;
-    uint32_t ns = g_subbatches; if (ns < 1) ns = 1; if (ns > 8) ns = 8;
+    uint32_t ns = g_subbatches; if (ns <= 1) ns = (uint32_t)env_int("ZKP_HIP_BP_SUBBATCHES", 1); if (ns < 1) ns = 1; if (ns > 8) ns = 8;
     D.nsub = ns;
     D.sub.resize((size_t)NSLOTS * ns);       // streams and events of a slot exist from its first use (ensure_sub)
     D.ready = true;

@@ -337,20 +337,25 @@ def test_fr9_constants_and_ntt_growth():
     mul = lambda a, b: a * b / rp + 1  # noqa: E731
     tab = mul(64, 1)                                  # fr9_from_fr: 32 * (value < 2r) times R9 mod r (< r)
     assert tab < F(14, 10)
-    # decimation in time, ten stages from a loaded / scaled element: u + v w and u - v w + 2r
-    b = tab
+    # The witness map (g16_steps.h: g16_qap_proof): load -> DIF inverse -> scale -> DIT forward -> pointwise -> DIF inverse -> coset_inv.
+    # decimation in frequency (first and last transform): reduce_weak(u + v) < 2.3, (u - v + 4r) w; inputs: loaded elements (< 1.4) / the
+    # pointwise result (< 1.3)
+    e = F(23, 10)
+    assert tab < e and e < 4 and mul(e + 4, tab) < e and 2 * e < rp
+    scaled = mul(e, tab)                              # the scale step: (element < 2.3 r) * coset table entry
+    assert scaled < F(11, 10)
+    # decimation in time, ten stages from a scaled element: u + v w and u - v w + 2r
+    b = scaled
     for _ in range(10):
         v = mul(b, tab)
         assert v < 2                                  # fr9_sub_k<2>
         b = b + 2
-    assert b < 22 and mul(b, tab) < F(12, 10)         # the scale step brings it back
-    # decimation in frequency: reduce_weak(u + v) < 2.3, (u - v + 4r) w
-    e = F(23, 10)
-    assert e < 4 and mul(e + 4, tab) < e and 2 * e < rp
-    # pointwise: a b - c + 4r, times zinv
-    assert mul(mul(e, e) + 4, tab) < F(11, 10)
-    # back to eight words: fr9_to_fr of (element < 22 r) * coset_inv stays below 2r
-    assert mul(mul(22, tab), 1) < 2
+    assert b < 22
+    # pointwise: (a b - c + 32 r) zinv with a, b, c outputs of the ten DIT stages
+    ab = mul(b, b)
+    assert ab < 4 and b < 32 and mul(ab + 32, tab) < F(13, 10) and mul(ab + 32, tab) < e
+    # back to eight words: fr9_to_fr of (element < 2.3 r) * coset_inv stays below 2r
+    assert mul(mul(e, tab), 1) < 2
     # fr9_reduce_weak: q = floor(top * floor(2^264 / r) / 2^32) never exceeds floor(a / r) and misses it by less than 1.3
     recip = (1 << 264) // R_
     for a in (R_ - 1, 2 * R_, 5 * R_ + 12345, (1 << 261) - 1, 44 * R_ - 1):
