@@ -32,7 +32,10 @@ struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
     static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int16_t)(word >> (16 * (w & 1u))); }
     using Acc = g2_jac;
     static __device__ __forceinline__ Acc identity() { return jac_infinity<fq2>(); }
-    static constexpr uint32_t GATHER_WAVES = 2; static constexpr int GATHER_PREFETCH = 0;     // k_msm_gather: the addition itself takes 239 VGPRs, entries are fetched at use
+#ifndef ZKP_G2_GATHER_PREFETCH
+#define ZKP_G2_GATHER_PREFETCH (-1)
+#endif
+    static constexpr uint32_t GATHER_WAVES = 2; static constexpr int GATHER_PREFETCH = ZKP_G2_GATHER_PREFETCH;     // k_msm_gather: the addition itself takes ~240 VGPRs; entries one step ahead through LDS
     // the gather loop: XYZZ coordinates over Fq2 on nine 29-bit limbs (bn254_g.h: g2_mmadd9); table entries are the four
     // coordinates x.c0, x.c1, y.c0, y.c1 packed into eight words each: 128 bytes, one cache line
     static constexpr uint32_t GATHER_W = 32;
@@ -190,8 +193,12 @@ uint32_t g16_msm_rows_per_block(bool) { return 256u; }
 uint32_t g16_msm_blocks_per_cu(bool g2) { return g2 ? G2Msm::GATHER_WAVES : G1Msm::GATHER_WAVES; }
 void g16_launch_msm(bool g2, const MsmView& m, hipStream_t st) {      // HBM-resident tables, per-lane gathers; m.nwin / nent / digw = the key's radix
     const uint32_t ngroups = (m.rows + 255u) / 256u, nblocks = m.nchunks * ngroups, grid = ((nblocks + 7) / 8) * 8;
-    if (!g2) k_msm_gather<G1Msm><<<grid, 256, 0, st>>>(m, ngroups, nblocks);
-    else k_msm_gather<G2Msm><<<grid, 256, 0, st>>>(m, ngroups, nblocks);
+    if constexpr (gather_lds_bytes<G2Msm>() > 0 || gather_lds_bytes<G1Msm>() > 0) {      // opt in to the dynamic LDS of the DMA-prefetch form (every call: the attribute is per device)
+        if (gather_lds_bytes<G1Msm>()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_gather<G1Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather_lds_bytes<G1Msm>());
+        if (gather_lds_bytes<G2Msm>()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_gather<G2Msm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)gather_lds_bytes<G2Msm>());
+    }
+    if (!g2) k_msm_gather<G1Msm><<<grid, 256, gather_lds_bytes<G1Msm>(), st>>>(m, ngroups, nblocks);
+    else k_msm_gather<G2Msm><<<grid, 256, gather_lds_bytes<G2Msm>(), st>>>(m, ngroups, nblocks);
 }
 void g16_launch_sum(bool g2, const ReduceView& R, uint32_t* sums, hipStream_t st) {
     const dim3 grid((R.rows + G16_SUM_ROWS - 1) / G16_SUM_ROWS, R.ntargets);

@@ -85,7 +85,9 @@ __global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint
 // walk the same sub-tables at the same time, so a good part of the entries is served from that XCD's L2).  No LDS, no
 // barrier: a workgroup is four independent waves.  Loads are software-pipelined when the point type has the registers for it
 // (T::GATHER_PREFETCH = number of steps of lead, 0 / 1 / 2): an entry's 16-byte pieces are issued one or two additions (~10 us each)
-// before the addition that consumes them; the digit word that selects them is fetched earlier still.
+// before the addition that consumes them; the digit word that selects them is fetched earlier still.  T::GATHER_PREFETCH = -1: one step
+// of lead through LDS by DMA (no staging registers; gather_lds_bytes<T>() of dynamic LDS per workgroup).
+template <class T> constexpr size_t gather_lds_bytes() { return T::GATHER_PREFETCH < 0 ? (size_t)4 * 2 * (T::GATHER_W / 4) * 64 * 16 : 0; }
 template <class T>
 __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, uint32_t ngroups, uint32_t nblocks) {
     constexpr uint32_t V4 = T::GATHER_W / 4;          // 16-byte pieces of one packed table entry (G1: 64 bytes, G2: 128)
@@ -111,6 +113,43 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
     if (left == 0) { if (active) T::store(m.partial, chunk, row, m.rows, T::from_gather(acc)); return; }
     uint32_t dw = digit_word(s, w);                               // the chunk may start in the middle of a word
     int32_t d = T::digit(dw, w);
+    if constexpr (T::GATHER_PREFETCH < 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // Entries one step ahead THROUGH LDS (the G2 loop has no registers to spare: 241 VGPRs at two waves per SIMD, so without this the
+        // gather of a step was issued when the step began and its HBM latency -- 2-3 us of a ~10 us addition -- was exposed on every
+        // step).  global_load_lds_dwordx4 moves each lane's 16-byte pieces straight into LDS, no VGPR in between: piece k of the 64 lanes
+        // of a wave lands as one contiguous KiB (lane l at + 16 l), two buffers per wave, 64 KB per workgroup for 128-byte entries.  A
+        // wave only reads what it wrote itself: no barrier, its own vmcnt(0) is the hand-over.
+        extern __shared__ uint4 gather_lds[];
+        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        uint4* const wbuf = gather_lds + (size_t)wave * (2u * V4 * 64u);
+        auto dma = [&](uint32_t buf, uint32_t slot, uint32_t win, int32_t dd) {
+            if (dd == 0) return;
+            const uint4* src = table4 + (((size_t)m.slot_base[slot] * m.nwin + win) * m.nent + (uint32_t)((dd < 0 ? -dd : dd) - 1)) * V4;
+            ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) __builtin_amdgcn_global_load_lds(src + k, wbuf + (buf * V4 + k) * 64u, 16, 0, 0);
+        };
+        uint32_t cb = 0;
+        dma(0, s, w, d);
+        while (left) {
+            const uint32_t nwin = m.slot_nwin[s];
+            uint32_t ns = s, nw = w + 1;
+            if (nw == nwin) { ns = s + 1; nw = 0; }
+            int32_t dn = 0;
+            if (left > 1) {
+                if ((nw % T::DIG_PER_WORD) == 0) dw = digit_word(ns, nw);
+                dn = T::digit(dw, nw);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this step's entry (issued a whole addition ago) and the digit word are there
+            uint4 e[V4];
+            if (d != 0) { ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) e[k] = wbuf[(cb * V4 + k) * 64u + lane]; }
+            if (left > 1) dma(cb ^ 1u, ns, nw, dn);                   // lands while this step's addition runs
+            if (d != 0) acc = T::accumulate_entry(acc, d, reinterpret_cast<const uint32_t*>(e));
+            cb ^= 1u; s = ns; w = nw; d = dn; left--;
+        }
+        if (active) T::store(m.partial, chunk, row, m.rows, T::from_gather(acc));
+        return;
+#endif
+    }
     uint4 cur[V4], nxt[V4];
     fetch(cur, s, w, d);
     if constexpr (T::GATHER_PREFETCH == 2) {

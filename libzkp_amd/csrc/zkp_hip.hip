@@ -12,6 +12,8 @@
 #include <type_traits>
 #include <atomic>
 #include <thread>
+#include <condition_variable>
+#include <functional>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -271,6 +273,27 @@ struct Device {
     };
     KProf prof[3];                      // ZKP_HIP_KERNEL_MSM_ED25519 / _BN254_G1 / _BN254_G2
     struct Trace* trace = nullptr;      // ZKP_HIP_TRACE=<file>: a timeline of every launch of a mixed batch (tools/trace_timeline.py)
+    struct ShardWorker* worker = nullptr;      // the host thread that drives this shard in multi-shard calls (created on first use, parked between calls)
+};
+// One parked host thread per shard: a multi-shard batch call (stage, prove, fetch = three fan-outs per batch) hands each shard's share to
+// that shard's worker instead of creating and joining a std::thread per shard per fan-out.  The thread touches HIP only inside a job; it is
+// never joined (nothing of this library is destroyed from exit(), see the registry below) and survives zkp_hip_shutdown parked.
+struct ShardWorker {
+    std::mutex mu; std::condition_variable cv;
+    std::function<void()> job; bool has_job = false, done = true;
+    std::thread th;
+    ShardWorker() : th([this]() { run(); }) { th.detach(); }
+    void run() {
+        for (;;) {
+            std::function<void()> f;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this]() { return has_job; }); f = std::move(job); has_job = false; }
+            f();
+            { std::lock_guard<std::mutex> lk(mu); done = true; }
+            cv.notify_all();
+        }
+    }
+    void post(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu); job = std::move(f); has_job = true; done = false; } cv.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this]() { return done; }); }
 };
 // event pair around one profiled launch (nullptrs when profiling is off)
 int prof_begin(Device::KProf& K, hipStream_t st, hipEvent_t* e1);

@@ -12,6 +12,7 @@ from util import P
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _lib(devices=None):
@@ -319,3 +320,45 @@ def test_missing_key_fails_before_anything_is_enqueued_and_a_retry_works():
     L = _lib()
     got = _run(L, *b)
     assert got[1] == want[1]
+
+
+def test_cu_partition_knob_and_launch_trace_leave_the_bytes_alone(tmp_path):
+    """ZKP_HIP_BP_CUS (the CU partition of mixed batches: masked streams, grids sized per partition; off by default) and ZKP_HIP_TRACE
+    (event records around every launch) change how a batch is scheduled, never what it proves.  Both are read once per process, so the
+    variant runs in a child process; the trace file must hold one line per proved batch with the kernels of every variant."""
+    import json
+    import subprocess
+    import sys
+    from libzkp_amd import _native
+    L = _lib()
+    ops, lists, seeds = wl.mixed_ops(1024, 61)                        # 256 of each variant: enough for the partition to engage
+    want = _run(L, ops, lists, seeds)
+    trace = str(tmp_path / "trace.jsonl")
+    code = r'''
+import ctypes, hashlib, os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from libzkp_amd import _native, workloads as wl
+from util import P
+L = _native.lib(); _native.check(L.zkp_hip_init(0), "init")
+for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")):
+    blob = open(os.path.join(%r, name), "rb").read(); assert L.zkp_hip_groth16_load_key(kind, blob, len(blob)) == 0
+ops, lists, seeds = wl.mixed_ops(1024, 61)
+cap = wl.max_output_bytes(ops); out = np.zeros(cap, dtype=np.uint8); off = np.zeros(1025, dtype=np.uint64); st = np.zeros(1024, dtype=np.int32)
+for _ in range(2):
+    assert L.zkp_hip_process_batch(1024, P(ops), P(lists), P(seeds), P(out), cap, P(off), P(st)) == 0
+print(hashlib.sha256(out[:int(off[-1])].tobytes()).hexdigest())
+L.zkp_hip_shutdown()
+''' % (ROOT_DIR, ROOT_DIR, GOLD)
+    import hashlib
+    digest = hashlib.sha256(b"".join(want[1])).hexdigest()
+    for extra in ({"ZKP_HIP_BP_CUS": "8"}, {"ZKP_HIP_TRACE": trace}):
+        env = dict(os.environ, ZKP_HIP_G16_WBITS="11", **extra)       # small tables: a second process on the GPU
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert p.stdout.strip().splitlines()[-1] == digest, extra
+    lines = [json.loads(x) for x in open(trace) if x.strip()]
+    assert len(lines) == 2
+    names = {r[0] for r in lines[-1]}
+    assert {"k_msm_dma<EdMsm>", "k_msm_gather<G1Msm>", "k_msm_gather<G2Msm>", "k_g16_qap", "k_stark_prove", "k_transcript_round"} <= names
+    assert all(r[3] >= r[2] >= 0 for r in lines[-1])
