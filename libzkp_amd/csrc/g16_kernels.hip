@@ -54,10 +54,12 @@ struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
 
 // ================================================================================================ kernels
 __global__ void __launch_bounds__(TW) k_g16_witness(G16View V) {
+    ZKP_RAISE_PRIO();
     const uint32_t row = blockIdx.x * TW + threadIdx.x;
     if (row < V.rows) step_g16_witness(V, row);
 }
 __global__ void __launch_bounds__(TB) k_g16_zdigits(G16View V) {
+    ZKP_RAISE_PRIO();
     const uint32_t row = blockIdx.x * TB + threadIdx.x;
     if (row < V.rows) step_g16_zdigits(V, blockIdx.y, row);
 }
@@ -72,10 +74,12 @@ __global__ void __launch_bounds__(QAP_TB) k_g16_qap(G16View V, G16Circuit C) {
     g16_qap_proof(V, C, L, blockIdx.x, threadIdx.x, QAP_TB, DevSync());
 }
 __global__ void __launch_bounds__(TW) k_g16_cparts(G16View V, const uint32_t* sum_g1, uint32_t* tmp_g1) {
+    ZKP_RAISE_PRIO();
     const uint32_t row = blockIdx.x * TW + threadIdx.x;
     if (row < V.rows) step_g16_cparts(V, sum_g1, tmp_g1, blockIdx.y, row);
 }
 __global__ void __launch_bounds__(TW) k_g16_final(G16View V, const uint32_t* sum_g1, const uint32_t* sum_g2, const uint32_t* tmp_g1) {
+    ZKP_RAISE_PRIO();
     const uint32_t row = blockIdx.x * TW + threadIdx.x;
     if (row < V.rows) step_g16_final(V, sum_g1, sum_g2, tmp_g1, blockIdx.y, row);
 }

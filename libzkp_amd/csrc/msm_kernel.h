@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
 // block needed two free wave slots' worth of registers on all four SIMDs of a CU at once and waited milliseconds for them).
 template <class T, uint32_t ROWS, uint32_t NTHREADS, uint32_t MIN_WAVES = 1>
 __global__ void __launch_bounds__(NTHREADS, MIN_WAVES) k_sum_t(ReduceView R, uint32_t* sums) {
+    ZKP_RAISE_PRIO();
     constexpr uint32_t SLICES = NTHREADS / ROWS;
     static_assert(NTHREADS % ROWS == 0 && (SLICES & (SLICES - 1)) == 0, "slices per row: a power of two");
     __shared__ uint32_t lds[T::ACC_W * (NTHREADS / 2)];              // [word][SLICES / 2 x ROWS]

@@ -27,3 +27,15 @@
 #ifndef ZKP_LAT_WAVES
 #define ZKP_LAT_WAVES 5
 #endif
+
+// Issue priority of a wave among the waves of its SIMD (s_setprio, 0..3; default 0).  The chain kernels -- a few waves each, their time is
+// instruction latency -- raise it: in a mixed batch they share SIMDs with MSM waves that would otherwise take three of every four issue
+// slots.  -DZKP_CHAIN_PRIO=0 builds without it (A/B).
+#ifndef ZKP_CHAIN_PRIO
+#define ZKP_CHAIN_PRIO 3
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZKP_RAISE_PRIO() __builtin_amdgcn_s_setprio(ZKP_CHAIN_PRIO)
+#else
+#define ZKP_RAISE_PRIO() ((void)0)
+#endif

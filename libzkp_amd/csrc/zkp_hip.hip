@@ -36,18 +36,22 @@
 
 __global__ void __launch_bounds__(TB) k_build_range(JobBuf J, uint32_t n, const uint64_t* value, const uint64_t* mn, const uint64_t* mx, uint32_t lg,
                                                     uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
+    ZKP_RAISE_PRIO();
     const uint32_t op = blockIdx.x * TB + threadIdx.x;
     if (op < n) step_build_range(J, op, value, mn, mx, lg, out, stride, out_len, status);
 }
 __global__ void __launch_bounds__(TB) k_ctask(CtView T) {
+    ZKP_RAISE_PRIO();
     const uint32_t c = blockIdx.x * TB + threadIdx.x;
     if (c < T.C) step_ctask(T, c);
 }
 __global__ void __launch_bounds__(TB) k_tape(BpView V) {
+    ZKP_RAISE_PRIO();
     const uint32_t job = blockIdx.x * TB + threadIdx.x;
     if (job < V.M) step_tape(V, blockIdx.y, job);
 }
 __global__ void __launch_bounds__(TB, ZKP_LAT_WAVES) k_poly(BpView V) {
+    ZKP_RAISE_PRIO();
     const uint32_t job = blockIdx.x * TB + threadIdx.x;
     if (job < V.M) step_poly(V, blockIdx.y, job);
 }
@@ -69,6 +73,7 @@ __device__ __forceinline__ ScTriple triple_tree8(ScTriple t, uint32_t* lds) {
     return t;
 }
 __global__ void __launch_bounds__(TW, ZKP_LAT_WAVES) k_poly_sum(BpView V) {
+    ZKP_RAISE_PRIO();
     __shared__ uint32_t lds[24 * TW];
     const uint32_t job = blockIdx.x * 8 + (threadIdx.x & 7u), part = threadIdx.x >> 3;
     const bool active = job < V.M;
@@ -78,31 +83,37 @@ __global__ void __launch_bounds__(TW, ZKP_LAT_WAVES) k_poly_sum(BpView V) {
     if (active && part == 0) step_poly_sum_finish(V, job, t);
 }
 __global__ void __launch_bounds__(TB) k_lr_init(BpView V) {
+    ZKP_RAISE_PRIO();
     const uint32_t job = blockIdx.x * TB + threadIdx.x;
     if (job < V.M) step_lr_init(V, blockIdx.y, job);
 }
 __global__ void __launch_bounds__(TB, ZKP_LAT_WAVES) k_round_prep(BpView V, uint32_t r) {
+    ZKP_RAISE_PRIO();
     const uint32_t job = blockIdx.x * TB + threadIdx.x;
     if (job < V.M) step_round_prep(V, r, blockIdx.y, job);
 }
-__global__ void __launch_bounds__(TW, ZKP_LAT_WAVES) k_round_sum(BpView V, uint32_t r) {      // <= 64 additions per lane: the 8-lane split measured slower here
+__global__ void __launch_bounds__(TW, ZKP_LAT_WAVES) k_round_sum(BpView V, uint32_t r) {
+    ZKP_RAISE_PRIO();      // <= 64 additions per lane: the 8-lane split measured slower here
     const uint32_t job = blockIdx.x * TW + threadIdx.x;
     if (job < V.M) step_round_sum(V, r, job);
 }
 // transcript steps: STROBE image of lane t at lds[i * TW + t] (conflict-free: consecutive lanes, consecutive banks)
 __global__ void __launch_bounds__(TW) k_transcript1(BpView V) {
+    ZKP_RAISE_PRIO();
     __shared__ uint32_t lds[50 * TW];
     const uint32_t job = blockIdx.x * TW + threadIdx.x;
     Strobe s; s.base = lds + threadIdx.x; s.stride = TW; s.pos = 0; s.pos_begin = 0;
     if (job < V.M) step_transcript1(V, job, s);
 }
 __global__ void __launch_bounds__(TW) k_transcript2(BpView V) {
+    ZKP_RAISE_PRIO();
     __shared__ uint32_t lds[50 * TW];
     const uint32_t job = blockIdx.x * TW + threadIdx.x;
     Strobe s; s.base = lds + threadIdx.x; s.stride = TW; s.pos = 0; s.pos_begin = 0;
     if (job < V.M) step_transcript2(V, job, s);
 }
 __global__ void __launch_bounds__(TW) k_transcript_round(BpView V, uint32_t r) {
+    ZKP_RAISE_PRIO();
     __shared__ uint32_t lds[50 * TW];
     const uint32_t job = blockIdx.x * TW + threadIdx.x;
     Strobe s; s.base = lds + threadIdx.x; s.stride = TW; s.pos = 0; s.pos_begin = 0;
@@ -113,6 +124,7 @@ __global__ void __launch_bounds__(TW) k_transcript_round(BpView V, uint32_t r) {
 // (Point addition is associative and the encoding canonical, so the bytes equal reduce_encode_thread's sequential sum,
 // which the host emulation uses.)
 __global__ void __launch_bounds__(TW) k_encode(ReduceView R, const uint32_t* sums) {
+    ZKP_RAISE_PRIO();
     const uint32_t row = blockIdx.x * TW + threadIdx.x, target = blockIdx.y;
     if (row >= R.rows) return;
     sc e; ge_ristretto_encode(e.v, ld_ge(sums, target, row, R.rows));
