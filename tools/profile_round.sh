@@ -2,7 +2,7 @@
 # kt:    kernel trace + stats of the overlapped run (B = python3 bench.py --steps N --warmup 1 --no-cpu-baseline --no-extra-legs)
 # pmc_*: separate counter passes (they serialise the dispatches: every kernel alone on the GPU) -- SQ issue/wait, LDS, FETCH_SIZE, WRITE_SIZE
 # then the library's own launch trace (ZKP_HIP_TRACE: a timeline without the profiler's per-dispatch host cost) and the default bench line.
-cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && O=$R/gpurun_out/r3v2 && mkdir -p $O && cd $R \
+cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && O=$R/gpurun_out/r3v3 && mkdir -p $O && cd $R \
 && rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra-legs > $O/bench_under_rocprof.json 2>$O/err_kt.txt \
 && python3 tools/timeline.py $O/kt/p_kernel_trace.csv > $O/timeline_rocprof.txt \
 && rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_s -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs > /dev/null 2>$O/err_s.txt \
