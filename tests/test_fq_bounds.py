@@ -275,6 +275,11 @@ def test_g1_mmadd9_is_closed_over_its_value_bounds():
     assert max(Pv, Rv, X3, Q + 8) < rp / 8
     # conversions: fq9_from_fq of a reduce_weak value (< 3p) starts inside the bounds; entries negated as 4p - y with y < 3p
     assert 3 < 4 and 3 <= X and 3 <= Y and 3 <= ZZ
+    # key-table entries (k_g16_build_table): an affine coordinate is an fq_mul output of safe operands (< 4p each: < 16 p / 84.6 + p
+    # = 1.19 p in ten-limb form), doubled by fq9_from_fq: < 2.4 p < 2^255 -- so the nine-limb integer fits the eight packed words of
+    # fq9_pack8 (its top limb stays below 2^24), and after fq9_unpack8 it is inside the entry bound above
+    entry = 2 * (F(16 * P, 1 << 260) + 1)
+    assert entry < F(24, 10) and entry * P < 1 << 255 and entry < qx
 
 
 def test_g2_mmadd9_is_closed_over_its_value_bounds():
