@@ -237,7 +237,9 @@ def main():
             if self.overlap:
                 self.pending[b] = w
             else:
-                w.wait()
+                w.wait()                                              # (on the GPU this only orders torch's stream behind the collective ...)
+                if self.all[b].is_cuda:
+                    torch.cuda.current_stream().synchronize()         # ... so block the host as well: nothing of the next step may run under this gather
 
         def drain(self):
             for b in range(len(self.pending)):                       # every gather issued so far has landed before the clock is read
