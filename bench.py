@@ -390,7 +390,7 @@ def main():
         L.zkp_hip_shutdown()
         try:
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-in-library", devices, "--c5-batch", str(args.c5_batch), "--steps", str(args.steps)],
-                               capture_output=True, text=True, timeout=420)
+                               capture_output=True, text=True, timeout=180)
             lines = [x for x in p.stdout.splitlines() if x.startswith("{")]
             extra["in_library_shards"] = json.loads(lines[-1]) if p.returncode == 0 and lines else {"error": "child exited with %d: %s" % (p.returncode, p.stderr[-400:])}
         except Exception as e:  # noqa: BLE001  (a timeout or anything else: reported, never fatal)
