@@ -1,7 +1,28 @@
-// Host-callable launcher of the Groth16 verification kernels (g16_verify_kernels.hip).
+// Host-callable launchers of the Groth16 verification kernels (g16_verify_kernels.hip: one lane per chain; fq2vm_kernels.hip: the
+// Fq2 virtual machine, K waves per chain).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include "g16_verify.h"
 
 size_t g16_verify_scratch_bytes(uint32_t n);     // device scratch for n envelopes (Miller-loop values, parsed points)
 void g16_launch_verify(int kind, const uint8_t* d_in, uint64_t stride, const uint32_t* d_len, uint32_t n, const zkp::G16Vk& vk, void* d_scratch, uint8_t* d_ok, hipStream_t st);
+
+// ---- Fq2 virtual machine (fq2vm.h): micro-operation tables in device memory, one set per device
+struct G16VmTables {
+    const uint32_t *code = nullptr, *off = nullptr;                                 // four waves per chain (fq2vm_programs.h)
+    const uint32_t* consts = nullptr;
+    const uint16_t* script[4] = {nullptr, nullptr, nullptr, nullptr};               // chain A, subgroup, finish, chain B
+    hipStream_t side[2] = {nullptr, nullptr}; hipEvent_t ev[3] = {nullptr, nullptr, nullptr};      // chain B and the subgroup chain run beside chain A
+    bool ready = false;
+};
+int g16_vm_upload(G16VmTables& T);
+void g16_vm_free(G16VmTables& T);
+// per key: the machine's Miller value of (beta, -alpha) and the line table of gamma and delta (host computation through the same tables)
+void g16_vm_key_constants(const zkp::g2_aff& beta, const zkp::g1_aff& neg_alpha, const zkp::g2_aff& gamma, const zkp::g2_aff& delta, uint32_t ml[6 * 20], std::vector<uint32_t>& lines);
+size_t g16_vm_scratch_bytes(uint32_t n);
+zkp::G16Pairs* g16_vm_pairs(void* d_scratch, uint32_t n);
+// verdicts of the generic envelopes in d_ok (0 for the others); *d_special (zeroed by the caller) counts the envelopes with a point at infinity in
+// the proof, whose verdicts only g16_launch_verify gives
+void g16_launch_verify_vm(int kind, const uint8_t* d_in, uint64_t stride, const uint32_t* d_len, uint32_t n, const zkp::G16Vk& vk, const G16VmTables& T, const uint32_t* d_kconst,
+                          const uint32_t* d_lines, void* d_scratch, uint8_t* d_ok, uint32_t* d_special, hipStream_t st);

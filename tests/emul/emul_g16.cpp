@@ -2,6 +2,7 @@
 // tier can compare the full assignment z and the quotient coefficients h with the oracle.
 #include "../../libzkp_amd/csrc/g16_circuit.h"
 #include "../../libzkp_amd/csrc/g16_verify.h"
+#include "../../libzkp_amd/csrc/fq2vm.h"
 #include <vector>
 using namespace zkp;
 
@@ -55,8 +56,11 @@ int emul_g16_witness_qap(int kind, uint64_t value, const uint64_t* set_vals, uin
 
 // Groth16 verification of one envelope (kind 0 equality / 1 membership) under a verifying key given as raw affine
 // coordinates: alpha (16 words), beta / gamma / delta (32 each), ic (n_ic x 16)
-int emul_g16_verify(int kind, const uint8_t* env, uint32_t len, const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma, const uint32_t* delta,
-                    uint32_t n_ic, const uint32_t* ic) {
+// mode 0: g16_verify.h's lane-per-chain code; mode 4: the Fq2 machine (fq2vm.h) with its tables (four waves per chain),
+// every round's streams executed as the device executes them.  Returns the verdict, or 2 when the machine leaves the envelope to the
+// lane-per-chain path (a point at infinity in the proof).
+static int verify_with(int mode, int kind, const uint8_t* env, uint32_t len, const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma, const uint32_t* delta,
+                       uint32_t n_ic, const uint32_t* ic) {
     auto g1 = [](const uint32_t* w) { return g1_aff{fq_from_raw(w), fq_from_raw(w + 8)}; };
     auto g2 = [](const uint32_t* w) { return g2_aff{fq2{fq_from_raw(w), fq_from_raw(w + 8)}, fq2{fq_from_raw(w + 16), fq_from_raw(w + 24)}}; };
     std::vector<uint32_t> icm((size_t)n_ic * 20);
@@ -88,7 +92,48 @@ int emul_g16_verify(int kind, const uint8_t* env, uint32_t len, const uint32_t* 
         }
         vk.ic_table = tab.data();
     }
-    vk.ml_alpha_beta = miller_loop(g2(beta), aff_neg(g1(alpha)));
-    return g16_verify_envelope(kind, vk, env, len) ? 1 : 0;
+    if (mode == 0) {
+        vk.ml_alpha_beta = miller_loop(g2(beta), aff_neg(g1(alpha)));
+        return g16_verify_envelope(kind, vk, env, len) ? 1 : 0;
+    }
+    namespace vm = fq2vm;
+    G16Pairs o;
+    if (!(kind == G16_EQUALITY ? g16_equality_pairs(vk, env, len, o) : g16_membership_pairs(vk, env, len, o))) return 0;
+    if (o.present != 15u) return 2;
+    const vm::Tables T = vm::Tables{vm::CODE_K4, vm::OFF_K4, 4, &vm::CONSTS[0][0]};
+    const uint32_t* regs = vm::REGS_K4;
+    std::vector<uint32_t> io((size_t)vm::N_SLOTS * vm::FQ2_W, 0u), kc(6 * vm::FQ2_W);
+    auto put = [&](std::vector<uint32_t>& buf, uint32_t slot, const fq2& x) { vm::fq2_to_words(&buf[(size_t)slot * vm::FQ2_W], x); };
+    auto get = [&](uint32_t slot) { return vm::fq2_from_words(&io[(size_t)slot * vm::FQ2_W]); };
+    std::vector<uint32_t> lines;           // what the library computes when a key is loaded (fq2vm_kernels.hip does the same through g16_vm_key_constants)
+    {
+        auto run1 = [&](const uint16_t* script, uint32_t len, uint32_t regs_ix, std::vector<uint32_t>& buf) { vm::Launch L{T, script, len, 1, buf.data(), 0, nullptr}; vm::run_host(L, 0, regs[regs_ix]); };
+        std::vector<uint32_t> io2((size_t)vm::N_SLOTS * vm::FQ2_W, 0u);
+        const g2_aff b = g2(beta); const g1_aff na = aff_neg(g1(alpha));
+        put(io2, vm::SLOT_QX, b.x); put(io2, vm::SLOT_QY, b.y); put(io2, vm::SLOT_P, fq2{na.x, na.y});
+        run1(vm::SCRIPT_MILLER, sizeof(vm::SCRIPT_MILLER) / 2, 0, io2);
+        for (uint32_t k = 0; k < 6 * vm::FQ2_W; k++) kc[k] = io2[(size_t)vm::SLOT_F0 * vm::FQ2_W + k];
+        lines.assign((size_t)vm::N_LINE_SLOTS * vm::FQ2_W, 0u);
+        for (int j = 0; j < 2; j++) {
+            std::vector<uint32_t> io3((size_t)(vm::LINE_SLOT0 + vm::N_LINE_SLOTS) * vm::FQ2_W, 0u);
+            put(io3, vm::SLOT_QX, j ? vk.delta.x : vk.gamma.x); put(io3, vm::SLOT_QY, j ? vk.delta.y : vk.gamma.y);
+            run1(vm::SCRIPT_LINES, sizeof(vm::SCRIPT_LINES) / 2, 4, io3);
+            for (uint32_t st = 0; st < vm::N_LINE_SLOTS / 6; st++)
+                for (uint32_t k = 0; k < 3 * vm::FQ2_W; k++) lines[((size_t)6 * st + 3 * j) * vm::FQ2_W + k] = io3[((size_t)vm::LINE_SLOT0 + 6 * st) * vm::FQ2_W + k];
+        }
+    }
+    for (uint32_t j = 0; j < 3; j++) { put(io, vm::PAIR_SLOTS * j + vm::SLOT_QX, o.Q[j].x); put(io, vm::PAIR_SLOTS * j + vm::SLOT_QY, o.Q[j].y); put(io, vm::PAIR_SLOTS * j + vm::SLOT_P, fq2{o.P[j].x, o.P[j].y}); }
+    { vm::Launch L{T, vm::SCRIPT_MILLER, (uint32_t)(sizeof(vm::SCRIPT_MILLER) / 2), 1, io.data(), 0, nullptr}; vm::run_host(L, 0, regs[0]); }
+    { vm::Launch L{T, vm::SCRIPT_MILLER_B, (uint32_t)(sizeof(vm::SCRIPT_MILLER_B) / 2), 1, io.data() + (size_t)vm::PAIR_SLOTS * vm::FQ2_W, 0, lines.data()}; vm::run_host(L, 0, regs[3]); }
+    { vm::Launch L{T, vm::SCRIPT_SUBGROUP, (uint32_t)(sizeof(vm::SCRIPT_SUBGROUP) / 2), 1, io.data(), 0, nullptr}; vm::run_host(L, 0, regs[1]); }
+    { vm::Launch L{T, vm::SCRIPT_FINISH, (uint32_t)(sizeof(vm::SCRIPT_FINISH) / 2), 1, io.data(), 0, kc.data()}; vm::run_host(L, 0, regs[2]); }
+    bool good = !f_is_zero(get(vm::SLOT_SZ)) && f_is_zero(get(vm::SLOT_SH)) && !f_is_zero(get(vm::SLOT_SR));
+    good = good && fq2_eq(get(vm::SLOT_RES), fq2_one());
+    for (uint32_t k = 1; k < 6; k++) good = good && f_is_zero(get(vm::SLOT_RES + k));
+    return good ? 1 : 0;
 }
+int emul_g16_verify(int kind, const uint8_t* env, uint32_t len, const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma, const uint32_t* delta,
+                    uint32_t n_ic, const uint32_t* ic) { return verify_with(0, kind, env, len, alpha, beta, gamma, delta, n_ic, ic); }
+int emul_g16_verify_vm(int waves, int kind, const uint8_t* env, uint32_t len, const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma, const uint32_t* delta,
+                       uint32_t n_ic, const uint32_t* ic) { return verify_with(4, kind, env, len, alpha, beta, gamma, delta, n_ic, ic); }
 }

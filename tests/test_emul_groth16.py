@@ -9,6 +9,8 @@ import pytest
 from oracle.py import bn254 as b
 from oracle.py import groth16 as g
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 @pytest.fixture(scope="module")
 def libs():
@@ -326,3 +328,53 @@ def test_groth16_verifier_verdicts_equal_oracle(libs):
         n = int.from_bytes(bad[10:14], "little")
         emb = [int.from_bytes(bad[14 + 8 * i:22 + 8 * i], "little") for i in range(n)] if 0 < n <= 64 and len(bad) == 10 + 4 + 8 * n + 288 else the_set
         assert bool(lib.emul_g16_verify(1, bytes(bad), len(bad), *vm)) == g.verify_membership(bytes(bad), emb, SS) is False, pos
+
+
+def test_fq2_machine_verdicts_equal_the_lane_per_chain_verifier(libs):
+    """fq2vm.h + the generated tables (tools/gen_fq2vm.py), executed on the host round by round (four waves per chain, two
+    half-waves each), against g16_verify.h and the oracle on the same envelopes: valid, a flipped bit in every region, ark's flag rules."""
+    _, lib = libs
+    SS = bytes(range(32))
+    rnd = random.Random(3)
+    seed = bytes(range(9, 41))
+    r_, s_ = g.draw_fr(seed, 0x47313600, 0), g.draw_fr(seed, 0x47313600, 1)
+    pk = g.equality_key(SS)
+    va = _vk_args(pk)
+    v = 987654321
+    cm = g.commit_value_snark(v)
+    env = g.envelope(2, g.prove_with_trapdoor(pk, g.equality_circuit(v, v, int.from_bytes(cm, "little")), r_, s_), cm)
+    cases = [env]
+    for pos in (1, 12, 40, 80, 100, 150, 210, 240, 270, 297):
+        bad = bytearray(env); bad[pos] ^= 1 << rnd.randrange(6); cases.append(bytes(bad))
+    for last in (73, 201, 265):
+        flip = bytearray(env); flip[last] ^= 0x80; cases.append(bytes(flip))
+    inf = bytearray(env); inf[10:74] = bytes(63) + b"\x40"; cases.append(bytes(inf))          # A = the point at infinity: left to the other path
+    for waves in (4,):
+        seen = set()
+        for e in cases:
+            want = lib.emul_g16_verify(0, e, len(e), *va)
+            got = lib.emul_g16_verify_vm(waves, 0, e, len(e), *va)
+            assert got == 2 or got == want, (waves, e.hex())
+            seen.add(got)
+        assert seen == {0, 1, 2}
+    assert g.verify_equality_with_commitment(env, cm, SS)
+    pkm = g.membership_key(SS)
+    vm = _vk_args(pkm)
+    envm = g.prove_membership(25, [10, 20, 25, 30, 2**40], SS, seed)
+    assert lib.emul_g16_verify_vm(4, 1, envm, len(envm), *vm) == 1
+    bad = bytearray(envm); bad[200] ^= 4
+    assert lib.emul_g16_verify_vm(4, 1, bytes(bad), len(bad), *vm) == lib.emul_g16_verify(1, bytes(bad), len(bad), *vm) == 0
+
+
+def test_fq2_machine_generator_self_check():
+    """tools/gen_fq2vm.py --check: the traced formulas against the oracle's pairing (bilinearity, non-degeneracy, a twist point outside
+    the subgroup), and every schedule / register allocation against the traced program; the committed header is what the tool emits."""
+    import subprocess, sys, os, tempfile
+    tool = os.path.join(ROOT, "tools", "gen_fq2vm.py")
+    out = subprocess.run([sys.executable, tool, "--check"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "schedules ok" in out.stdout, out.stdout + out.stderr
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_fq2vm
+    with tempfile.TemporaryDirectory() as d:
+        gen_fq2vm.emit(os.path.join(d, "h"))
+        assert open(os.path.join(d, "h")).read() == open(os.path.join(ROOT, "libzkp_amd", "csrc", "fq2vm_programs.h")).read()

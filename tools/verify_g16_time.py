@@ -1,0 +1,40 @@
+"""Groth16 verification timing on one MI355X (development aid): proves n equality envelopes (and n // 4 membership envelopes with
+16-element sets), verifies each batch five times through the C ABI and prints the best wall time.  Under
+`rocprofv3 --kernel-trace --stats -- python3 tools/verify_g16_time.py` the kernel table shows where the time goes.
+Usage: verify_g16_time.py [n]"""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import libzkp_amd as z
+from libzkp_amd import _native, api
+L = _native.lib()
+_native.check(L.zkp_hip_init(0), "init")
+for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")):
+    api.install_proving_key(kind, open(os.path.join(ROOT, "tests", "golden", name), "rb").read())
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+rng = np.random.default_rng(11)
+
+
+def best(f, reps=5):
+    f()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); r = f(); ts.append(time.perf_counter() - t0)
+    return min(ts), r
+
+
+vals = [int(x) for x in rng.integers(0, 2**63, n)]
+ep = z.prove_equality_batch(vals, vals)
+dt, ok = best(lambda: api._verify_snark_envelopes(0, ep))
+assert all(ok)
+bad = [bytes(e[:40]) + bytes([e[40] ^ 1]) + bytes(e[41:]) for e in ep[:64]]
+assert not any(api._verify_snark_envelopes(0, bad))
+out = {"equality": {"n": n, "ms": round(dt * 1e3, 2), "envelopes_per_s": round(n / dt)}}
+m = max(1, n // 4)
+sets = [[int(x) for x in rng.choice(2**40, 16, replace=False)] for _ in range(m)]
+mp = z.prove_membership_batch([s[3] for s in sets], sets)
+dt, ok = best(lambda: z.verify_membership_batch(mp, sets))
+assert all(ok)
+out["membership"] = {"n": m, "set": 16, "ms": round(dt * 1e3, 2), "envelopes_per_s": round(m / dt)}
+print(json.dumps(out))
