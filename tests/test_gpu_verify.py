@@ -247,3 +247,67 @@ def test_groth16_verification(hip):
     comp = z.create_composite_proof([r, proofs[0], mp[0]])
     assert z.verify_composite_proof(comp)
     assert z.verify_proofs_parallel([(proofs[1], "equality"), (mp[1], "membership"), (bad[1], "equality"), (proofs[2], "membership")]) == [True, True, False, False]
+
+
+_G16_PATHS_CHILD = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import libzkp_amd as z
+import libzkp_amd.api as api
+gold = os.path.join(sys.argv[1], "tests", "golden")
+for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")):
+    api.install_proving_key(kind, open(os.path.join(gold, name), "rb").read())
+blobs = [bytes.fromhex(h) for h in json.load(open(sys.argv[2]))]
+mblobs = [bytes.fromhex(h) for h in json.load(open(sys.argv[3]))]
+print(json.dumps([api._verify_snark_envelopes(0, blobs[:-8]), api._verify_snark_envelopes(0, blobs), api._verify_snark_envelopes(1, mblobs)]))
+"""
+
+
+def test_groth16_machine_and_lane_per_chain_paths_agree(hip, tmp_path):
+    """The Fq2 machine (fq2vm.h: the default) and the lane-per-chain kernels (ZKP_HIP_G16_VERIFY_VM=0, a fresh process) give the same
+    verdicts on valid, bit-flipped and malleated envelopes; a batch that holds proofs with a point at infinity (valid encodings that
+    the machine leaves to the other kernels) still gets every verdict right; a sample is checked against the oracle's verifier."""
+    import json, os, subprocess, sys
+    import libzkp_amd as z
+    import libzkp_amd.api as api
+    from oracle.py import groth16 as g
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")):
+        api.install_proving_key(kind, open(os.path.join(gold, name), "rb").read())
+    SS = bytes(range(32))
+    rng = np.random.default_rng(77)
+    vals = [int(x) for x in rng.integers(0, 2**63, 150, dtype=np.uint64)]
+    proofs = z.prove_equality_batch(vals, vals)
+    blobs = list(proofs[:70])
+    for p in proofs[70:150]:                                   # one to three flipped bits anywhere in the envelope
+        b = bytearray(p)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, 298))] ^= 1 << int(rng.integers(0, 8))
+        blobs.append(bytes(b))
+    for last in (73, 201, 265):
+        b = bytearray(proofs[0]); b[last] ^= 0x80; blobs.append(bytes(b))
+    inf1 = bytes(63) + b"\x40"
+    special = []
+    for off, size in ((10, 64), (74, 128), (202, 64)):         # A, B, C replaced by the point at infinity
+        b = bytearray(proofs[1]); b[off:off + size] = (bytes(size - 1) + b"\x40"); special.append(bytes(b))
+    special += [bytes(bytearray(proofs[2][:10]) + inf1 + bytearray(proofs[2][74:]))] * 5
+    blobs += special                                            # the last eight: present only in the second call of the child
+    sets = [[int(x) for x in rng.choice(2**32, 7, replace=False)] for _ in range(20)]
+    mp = z.prove_membership_batch([s[i % 7] for i, s in enumerate(sets)], sets)
+    mblobs = list(mp[:10])
+    for p in mp[10:]:
+        b = bytearray(p); b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8)); mblobs.append(bytes(b))
+    f1, f2 = tmp_path / "eq.json", tmp_path / "mem.json"
+    f1.write_text(json.dumps([b.hex() for b in blobs])); f2.write_text(json.dumps([b.hex() for b in mblobs]))
+    got = [api._verify_snark_envelopes(0, blobs[:-8]), api._verify_snark_envelopes(0, blobs), api._verify_snark_envelopes(1, mblobs)]
+    env = dict(os.environ, ZKP_HIP_G16_VERIFY_VM="0")
+    out = subprocess.run([sys.executable, "-c", _G16_PATHS_CHILD, root, str(f1), str(f2)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lane = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got == lane
+    assert got[0][:70] == [True] * 70 and got[0][150:153] == [True] * 3 and got[2][:10] == [True] * 10
+    assert got[1][:len(got[0])] == got[0] and not any(got[1][-8:])
+    for i in list(range(66, 78)) + list(range(150, 161)):
+        assert got[1][i] == g.verify_equality_with_commitment(blobs[i], blobs[i][266:], SS), i
