@@ -1,7 +1,7 @@
 """Groth16 verification timing on one MI355X (development aid): proves n equality envelopes (and n // 4 membership envelopes with
 16-element sets), verifies each batch five times through the C ABI and prints the best wall time.  Under
 `rocprofv3 --kernel-trace --stats -- python3 tools/verify_g16_time.py` the kernel table shows where the time goes.
-Usage: verify_g16_time.py [n]"""
+Usage: verify_g16_time.py [n] [--sweep]   (--sweep: also equality batches of 1024 / 16384 / 65536 envelopes, cycled copies of the n proved)"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,8 @@ L = _native.lib()
 _native.check(L.zkp_hip_init(0), "init")
 for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")):
     api.install_proving_key(kind, open(os.path.join(ROOT, "tests", "golden", name), "rb").read())
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if args else 4096
 rng = np.random.default_rng(11)
 
 
@@ -37,4 +38,11 @@ mp = z.prove_membership_batch([s[3] for s in sets], sets)
 dt, ok = best(lambda: z.verify_membership_batch(mp, sets))
 assert all(ok)
 out["membership"] = {"n": m, "set": 16, "ms": round(dt * 1e3, 2), "envelopes_per_s": round(m / dt)}
+if "--sweep" in sys.argv:
+    out["equality_sweep"] = {}
+    for m2 in (1024, 16384, 65536):
+        batch = [ep[i % n] for i in range(m2)]
+        dt, ok = best(lambda: api._verify_snark_envelopes(0, batch), reps=3)
+        assert all(ok)
+        out["equality_sweep"][str(m2)] = {"ms": round(dt * 1e3, 2), "envelopes_per_s": round(m2 / dt)}
 print(json.dumps(out))
