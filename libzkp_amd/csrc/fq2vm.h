@@ -126,10 +126,13 @@ __device__ inline void run_device(const Launch& L, uint32_t* __restrict__ regs) 
             case INV: st(on, d, f_inv(ld(a))); break;
             case NEG: st(on, d, f_neg(ld(a))); break;
             case MOV: st(on, d, ld(a)); break;
-            case LDG: if (on) { ZKP_UNROLL for (uint32_t k = 0; k < FQ2_W; k++) regs[(d * FQ2_W + k) * G + gl] = inb ? io[((size_t)b * FQ2_W + k) * L.n + i] : 0u; } break;
+            // loads from memory: all twenty words are requested before the first is stored (one memory latency per operation, not twenty)
+            case LDG: { uint32_t t[FQ2_W]; ZKP_UNROLL for (uint32_t k = 0; k < FQ2_W; k++) t[k] = inb ? io[((size_t)b * FQ2_W + k) * L.n + i] : 0u;
+                        if (on) { ZKP_UNROLL for (uint32_t k = 0; k < FQ2_W; k++) regs[(d * FQ2_W + k) * G + gl] = t[k]; } break; }
             case STG: case STC: if (on && inb) { const size_t sl = b + (op == STC ? cur : 0u); ZKP_UNROLL for (uint32_t k = 0; k < FQ2_W; k++) io[(sl * FQ2_W + k) * L.n + i] = regs[(a * FQ2_W + k) * G + gl]; } break;
-            case LDC: if (on) { ZKP_UNROLL for (uint32_t k = 0; k < FQ2_W; k++) regs[(d * FQ2_W + k) * G + gl] = L.T.consts[b * FQ2_W + k]; } break;
-            case LDK: if (on) { ZKP_UNROLL for (uint32_t k = 0; k < FQ2_W; k++) regs[(d * FQ2_W + k) * G + gl] = L.kconst[(cur + b) * FQ2_W + k]; } break;
+            case LDC: case LDK: { const uint32_t* src = op == LDC ? L.T.consts + b * FQ2_W : L.kconst + (size_t)(cur + b) * FQ2_W;
+                        uint32_t t[FQ2_W]; ZKP_UNROLL for (uint32_t k = 0; k < FQ2_W; k++) t[k] = src[k];
+                        if (on) { ZKP_UNROLL for (uint32_t k = 0; k < FQ2_W; k++) regs[(d * FQ2_W + k) * G + gl] = t[k]; } break; }
             default: break;
             }
             if (bar) __syncthreads();

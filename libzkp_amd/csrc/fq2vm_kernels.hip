@@ -47,8 +47,8 @@ __global__ void __launch_bounds__(64) k_g16_vm_verdict(uint32_t n, const uint32_
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     if (flags[i] != 1) { ok[i] = 0; if (flags[i] == 2) atomicAdd(special, 1u); return; }
-    // B in the subgroup: (r - 1) B is finite and equals -B (the last addition of r B meets H = 0 with r != 0; fq2vm_programs.h S_LAST)
-    bool good = !f_is_zero(vm_get(io, n, i, fq2vm::SLOT_SZ)) && f_is_zero(vm_get(io, n, i, fq2vm::SLOT_SH)) && !f_is_zero(vm_get(io, n, i, fq2vm::SLOT_SR));
+    // B in the subgroup: [6x^2] B is finite and equals psi(B) (tools/gen_fq2vm.py S_LAST: Z, and the differences of the two coordinates)
+    bool good = !f_is_zero(vm_get(io, n, i, fq2vm::SLOT_SZ)) && f_is_zero(vm_get(io, n, i, fq2vm::SLOT_SH)) && f_is_zero(vm_get(io, n, i, fq2vm::SLOT_SR));
     good = good && fq2_eq(vm_get(io, n, i, fq2vm::SLOT_RES), fq2_one());
     for (uint32_t k = 1; k < 6; k++) good = good && f_is_zero(vm_get(io, n, i, fq2vm::SLOT_RES + k));
     ok[i] = good ? 1 : 0;
@@ -126,15 +126,19 @@ void g16_launch_verify_vm(int kind, const uint8_t* d_in, uint64_t stride, const 
         fq2vm::Launch L{{T.code, T.off, K, T.consts}, T.script[chain], script_len, n, base, 0, kconst};
         k_fq2vm<<<ng, K * 64, (size_t)fq2vm::REGS_K4[chain] * fq2vm::FQ2_W * fq2vm::G * 4, s>>>(L);
     };
-    // chain B and the subgroup check of B run beside chain A on streams of their own (LDS of a workgroup: A 118 KB, B 115 KB, subgroup
-    // 38 KB: a CU holds A or B plus a subgroup workgroup); the final exponentiation needs A and B, the verdict also the subgroup check
+    // Chain B runs beside chain A on a stream of its own (a workgroup's LDS: A 118 KB, B 115 KB: one per CU, 128 + 128 workgroups per 4096
+    // envelopes).  The subgroup check of B (38 KB) only feeds the verdict and starts when chain A is done, beside the final exponentiation
+    // (159 KB per workgroup: it cannot share a CU with anything, the subgroup workgroups take the other CUs): launched together with A and
+    // B its waves shared the SIMDs of chain B's CUs and stretched B, which the final exponentiation waits for, from 3.4 to 5.2 ms.
     (void)hipEventRecord(T.ev[0], st);
-    (void)hipStreamWaitEvent(T.side[0], T.ev[0], 0); (void)hipStreamWaitEvent(T.side[1], T.ev[0], 0);
+    (void)hipStreamWaitEvent(T.side[0], T.ev[0], 0);
     launch(3, io + pair_words, d_lines, (uint32_t)(sizeof(fq2vm::SCRIPT_MILLER_B) / 2), T.side[0]);
     (void)hipEventRecord(T.ev[1], T.side[0]);
+    launch(0, io, nullptr, (uint32_t)(sizeof(fq2vm::SCRIPT_MILLER) / 2), st);
+    (void)hipEventRecord(T.ev[0], st);
+    (void)hipStreamWaitEvent(T.side[1], T.ev[0], 0);
     launch(1, io, nullptr, (uint32_t)(sizeof(fq2vm::SCRIPT_SUBGROUP) / 2), T.side[1]);
     (void)hipEventRecord(T.ev[2], T.side[1]);
-    launch(0, io, nullptr, (uint32_t)(sizeof(fq2vm::SCRIPT_MILLER) / 2), st);
     (void)hipStreamWaitEvent(st, T.ev[1], 0);
     launch(2, io, d_kconst, (uint32_t)(sizeof(fq2vm::SCRIPT_FINISH) / 2), st);
     (void)hipStreamWaitEvent(st, T.ev[2], 0);

@@ -127,7 +127,7 @@ static int verify_with(int mode, int kind, const uint8_t* env, uint32_t len, con
     { vm::Launch L{T, vm::SCRIPT_MILLER_B, (uint32_t)(sizeof(vm::SCRIPT_MILLER_B) / 2), 1, io.data() + (size_t)vm::PAIR_SLOTS * vm::FQ2_W, 0, lines.data()}; vm::run_host(L, 0, regs[3]); }
     { vm::Launch L{T, vm::SCRIPT_SUBGROUP, (uint32_t)(sizeof(vm::SCRIPT_SUBGROUP) / 2), 1, io.data(), 0, nullptr}; vm::run_host(L, 0, regs[1]); }
     { vm::Launch L{T, vm::SCRIPT_FINISH, (uint32_t)(sizeof(vm::SCRIPT_FINISH) / 2), 1, io.data(), 0, kc.data()}; vm::run_host(L, 0, regs[2]); }
-    bool good = !f_is_zero(get(vm::SLOT_SZ)) && f_is_zero(get(vm::SLOT_SH)) && !f_is_zero(get(vm::SLOT_SR));
+    bool good = !f_is_zero(get(vm::SLOT_SZ)) && f_is_zero(get(vm::SLOT_SH)) && f_is_zero(get(vm::SLOT_SR));
     good = good && fq2_eq(get(vm::SLOT_RES), fq2_one());
     for (uint32_t k = 1; k < 6; k++) good = good && f_is_zero(get(vm::SLOT_RES + k));
     return good ? 1 : 0;

@@ -32,6 +32,14 @@ assert all(ok)
 bad = [bytes(e[:40]) + bytes([e[40] ^ 1]) + bytes(e[41:]) for e in ep[:64]]
 assert not any(api._verify_snark_envelopes(0, bad))
 out = {"equality": {"n": n, "ms": round(dt * 1e3, 2), "envelopes_per_s": round(n / dt)}}
+# the C ABI alone (the Python mirror's per-envelope marshalling left out): one strided buffer in, verdict bytes out
+import ctypes
+P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+buf = np.zeros((n, 298), dtype=np.uint8); lens = np.full(n, 298, dtype=np.uint32); okb = np.zeros(n, dtype=np.uint8)
+for i, e in enumerate(ep): buf[i] = np.frombuffer(e, dtype=np.uint8)
+dt, _ = best(lambda: _native.check(L.zkp_hip_verify_equality_batch(n, P(buf), 298, P(lens), P(okb)), "verify"))
+assert okb.all()
+out["equality"]["c_abi_ms"] = round(dt * 1e3, 2); out["equality"]["c_abi_envelopes_per_s"] = round(n / dt)
 m = max(1, n // 4)
 sets = [[int(x) for x in rng.choice(2**40, 16, replace=False)] for _ in range(m)]
 mp = z.prove_membership_batch([s[3] for s in sets], sets)
