@@ -350,6 +350,8 @@ def build_programs():
     p = prog("F_CSQ"); out12(p, A, f12_cyclo_sq(in12(p, A)))
     p = prog("F_MULB")
     a, b = in12(p, A), in12(p, Bn); out12(p, A, f12_mul(a, b))
+    p = prog("F_MULC")          # acc * base^-1: in the cyclotomic subgroup the inverse is the conjugate (the powers walk x in signed digits)
+    a, b = in12(p, A), in12(p, Bn); out12(p, A, f12_mul(a, f12_conj(b)))
     # the values the chain comes back to (r, y1, y3, y4) wait in the slot buffer, not in registers: the power loops keep the whole
     # register file for the products of one Fq12 multiplication
     p = prog("F_G1")            # acc = r^x: y0 = conj, y1 = y0^2, y3 = y1^2 y1; next power on y3
@@ -404,11 +406,13 @@ def scripts():
         s.append("S_DBL")
         if ds[i]: s.append("S_ADD" if ds[i] > 0 else "S_SUB")
     s.append("S_LAST")
+    dx = naf(X)
+    assert dx[-1] == 1
     def powx():
         o = []
-        for b in bin(X)[3:]:
+        for i in range(len(dx) - 2, -1, -1):
             o.append("F_CSQ")
-            if b == "1": o.append("F_MULB")
+            if dx[i]: o.append("F_MULB" if dx[i] > 0 else "F_MULC")
         return o
     f = ["F_INIT"] + powx() + ["F_G1"] + powx() + ["F_G2"] + powx() + ["F_G3"]
     return {"miller": m, "subgroup": s, "finish": f, "miller_b": bb, "lines": ll}
