@@ -448,9 +448,9 @@ class Sched:
     pass
 
 
-def schedule(p, K, window, noise=None, budget0=None):
-    """rounds[r][w] = list of STEPS of wave w in round r; a step is one or two operations of the same opcode (the two halves of the
-    wave: lanes 0-31 and 32-63 work for the same 32 envelopes on different operands)."""
+def schedule(p, K, window, noise=None, budget0=None, slots=2):
+    """rounds[r][w] = list of STEPS of wave w in round r; a step is up to `slots` operations of the same opcode (the parts of the wave:
+    with two slots lanes 0-31 and 32-63 work for the same 32 envelopes on different operands; with four, 16 lanes each for 16 envelopes)."""
     n = len(p.ops)
     defs = {}
     for i, (op, d, a, b, imm) in enumerate(p.ops):
@@ -498,9 +498,9 @@ def schedule(p, K, window, noise=None, budget0=None):
                     if not ws: continue
                     w = min(ws, key=lambda q: loads[q])
                 step = [i]
-                if PAIR:
-                    for _, j, same2 in ready:
-                        if j != i and p.ops[j][0] == p.ops[i][0] and (same2 is None or same2 == w): step.append(j); break
+                for _, j, same2 in ready:
+                    if len(step) == slots: break
+                    if j != i and p.ops[j][0] == p.ops[i][0] and (same2 is None or same2 == w): step.append(j)
                 lanes[w].append(step); loads[w] += cost[i]; progress = True
                 for q in step: placed[q] = w
                 budget = max(budget, loads[w])
@@ -512,12 +512,11 @@ def schedule(p, K, window, noise=None, budget0=None):
     return rounds, done_round
 
 
-PAIR = True
 
 
-def allocate(p, rounds, done_round, pins, nreg):
-    """pins: name -> physical register.  Returns (streams, nused): streams[w] = list of [op, (d, a, b), (d, a, b) or None, bar] with
-    physical registers (b = the immediate of LDG / STG / LDC / LDK)."""
+def allocate(p, rounds, done_round, pins, nreg, slots=2):
+    """pins: name -> physical register.  Returns (streams, nused): streams[w] = list of [op, [(d, a, b), ...], bar] with physical registers
+    (one triple per occupied slot of the step; b = the immediate of LDG / STG / LDC / LDK)."""
     K = len(rounds[0])
     last_use = {}
     for i, (op, d, a, b, imm) in enumerate(p.ops):
@@ -566,15 +565,15 @@ def allocate(p, rounds, done_round, pins, nreg):
     for r, lanes in enumerate(rounds):
         for w in range(K):
             for step in lanes[w]:
-                streams[w].append([p.ops[step[0]][0], triple(step[0]), triple(step[1]) if len(step) > 1 else None, 0])
-            if not lanes[w]: streams[w].append([NOP, (0, 0, 0), None, 0])
-            streams[w][-1][3] = 1
+                streams[w].append([p.ops[step[0]][0], [triple(i) for i in step], 0])
+            if not lanes[w]: streams[w].append([NOP, [(0, 0, 0)], 0])
+            streams[w][-1][2] = 1
     # fix-up: outputs that are not yet in their pins
     moves = []
     for v, names in out_of.items():
         for nme in names:
             if phys[v] != pins[nme]: moves.append((pins[nme], phys[v]))
-    per = 2 if PAIR else 1
+    per = slots
     while moves:                                         # a copy may only overwrite a register that no remaining copy still reads
         srcs = {s for d, s in moves}
         ready = [m for m in moves if m[0] not in srcs]
@@ -582,8 +581,8 @@ def allocate(p, rounds, done_round, pins, nreg):
         ready = ready[:K * per]
         for w in range(K):
             mine = ready[w * per:(w + 1) * per]
-            if mine: streams[w].append([MOV, (mine[0][0], mine[0][1], 0), (mine[1][0], mine[1][1], 0) if len(mine) > 1 else None, 1])
-            else: streams[w].append([NOP, (0, 0, 0), None, 1])
+            if mine: streams[w].append([MOV, [(m[0], m[1], 0) for m in mine], 1])
+            else: streams[w].append([NOP, [(0, 0, 0)], 1])
         moves = [m for m in moves if m not in ready]
     return streams, (len(pins) - len([1 for q in reusable if q not in live_in_pins])) + peak
 
@@ -600,11 +599,11 @@ def simulate(streams, regs, gmem, cur=0):
         for w in range(K):
             local = {}
             while True:
-                op, h0, h1, bar = streams[w][pc[w]]; pc[w] += 1
+                op, hs, bar = streams[w][pc[w]]; pc[w] += 1
                 get = lambda x: local[x] if x in local else regs[x]
                 results = []
-                for h in (h0, h1):
-                    if h is None or op == NOP: continue
+                for h in hs:
+                    if op == NOP: continue
                     d, a, b = h
                     if op == LDG: results.append((d, gmem[b]))
                     elif op == LDC: results.append((d, CONSTS[b]))
@@ -616,8 +615,7 @@ def simulate(streams, regs, gmem, cur=0):
                         for x in ((a, b) if op in two else (a,)):
                             if x not in local: reads[w].add(x)
                         results.append((d, apply_op(op, get(a), get(b) if op in two else None)))
-                if len(results) == 2:
-                    assert results[0][0] != results[1][0], "the halves of a step write one register"
+                assert len({d for d, v in results}) == len(results), "two slots of a step write one register"
                 for d, v in results: local[d] = v; writes[w].add(d)
                 if bar: break
             new[w] = local
@@ -648,7 +646,7 @@ def estimate(streams):
         for w in range(K):
             l = 0
             while True:
-                op, h0, h1, bar = streams[w][pc[w]]; pc[w] += 1; l += COST[op] + 1
+                op, hs, bar = streams[w][pc[w]]; pc[w] += 1; l += COST[op] + 1
                 if bar: break
             mx = max(mx, l)
         tot += mx + 2
@@ -673,8 +671,8 @@ def compile_all(K, nreg, verbose=False, search=True):
                                rnd.choice([COST[MUL], COST[MUL], COST[MUL] * 3 // 2, COST[MUL] * 2])))
         best = None
         for window, noise, budget0 in trials:
-            rounds, done = schedule(p, K, window, noise, budget0)
-            streams, used = allocate(p, rounds, done, pm, nreg[name[0]])
+            rounds, done = schedule(p, K, window, noise, budget0, SLOTS[name[0]])
+            streams, used = allocate(p, rounds, done, pm, nreg[name[0]], SLOTS[name[0]])
             if streams is None: continue
             e = estimate(streams)
             if best is None or e < best[4]: best = (streams, used, window, len(rounds), e)
@@ -783,7 +781,11 @@ def f2sqrt(a):
     return f2mul(b, x0)
 
 
-NREG = {"M": 46, "S": 16, "F": 62, "B": 46, "L": 24}       # what the LDS holds with 32 envelopes per workgroup: 46 x 80 bytes x 32 (Miller) + 16 x 80 x 32 (subgroup) on one CU; 62 x 80 x 32 (finish)
+NREG = {"M": 46, "S": 16, "F": 62, "B": 46, "L": 24}
+# slots of a wave (= operations of one opcode it runs at a time): two = 32 envelopes per workgroup.  (Four slots = 16 envelopes per workgroup were
+# scheduled for the final exponentiation -- 256 workgroups instead of 128 per 4096 envelopes, 124 registers: the estimate drops by 18 %, its
+# squarings are bound by their dependency chain; the interpreter has no four-slot form.)
+SLOTS = {"M": 2, "S": 2, "F": 2, "B": 2, "L": 2}       # what the LDS holds with 32 envelopes per workgroup: 46 x 80 bytes x 32 (Miller) + 16 x 80 x 32 (subgroup) on one CU; 62 x 80 x 32 (finish)
 
 
 # ---------------------------------------------------------------- emission
@@ -797,9 +799,9 @@ def emit(path, Ks=(4,)):
     L = []
     L.append("// GENERATED by tools/gen_fq2vm.py -- do not edit.  Micro-operation tables of the Fq2 virtual machine (fq2vm.h): the Groth16")
     L.append("// verifier's Miller loops (optimal ate, loop count 6x + 2 in NAF: chain A = a pair with a proof's G2 point, chain B = the two pairs on the")
-    L.append("// key's gamma and delta over line tables that chain L computes per key), G2 subgroup check (r * Q) and final exponentiation (x-chain),")
-    L.append("// scheduled for K cooperating wavefronts.  A micro-operation is two words: op | barrier << 7 | dst << 8 | a << 16 | b << 24 for lanes 0-31 of the")
-    L.append("// wave, then present | dst << 8 | a << 16 | b << 24 for lanes 32-63 (the same opcode on other registers of the same 32 envelopes).")
+    L.append("// key's gamma and delta over line tables that chain L computes per key), G2 subgroup check (psi(Q) = [6x^2] Q) and final exponentiation (x-chain, signed digits),")
+    L.append("// scheduled for K cooperating wavefronts.  A micro-operation is one word per slot of the wave: op | barrier << 7 | dst << 8 | a << 16 | b << 24 for")
+    L.append("// the first slot, then present | dst << 8 | a << 16 | b << 24 for the others (the same opcode on other registers of the same envelopes).")
     L.append("#pragma once")
     L.append("#include <cstdint>")
     L.append("namespace zkp { namespace fq2vm {")
@@ -813,11 +815,12 @@ def emit(path, Ks=(4,)):
             streams = comp[name][0]
             for w in range(K):
                 off.append(len(code))
-                for op, h0, h1, bar in streams[w]:
-                    assert all(x < 256 for x in h0) and (h1 is None or all(x < 256 for x in h1))
-                    code.append(op | (BAR if bar else 0) | h0[0] << 8 | h0[1] << 16 | h0[2] << 24)
-                    code.append((1 | h1[0] << 8 | h1[1] << 16 | h1[2] << 24) if h1 is not None else 0)
-                code += [END, 0]
+                ns = SLOTS[name[0]]
+                for op, hs, bar in streams[w]:
+                    assert all(x < 256 for h in hs for x in h) and len(hs) <= ns
+                    code.append(op | (BAR if bar else 0) | hs[0][0] << 8 | hs[0][1] << 16 | hs[0][2] << 24)
+                    for q in range(1, ns): code.append((1 | hs[q][0] << 8 | hs[q][1] << 16 | hs[q][2] << 24) if q < len(hs) else 0)
+                code += [END] + [0] * (ns - 1)
         L.append("static const uint32_t CODE_K%d[%d] = {" % (K, len(code)))
         for i in range(0, len(code), 12): L.append("    " + ", ".join("0x%08xu" % c for c in code[i:i + 12]) + ",")
         L.append("};")
