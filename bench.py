@@ -343,6 +343,25 @@ def main():
             extra["other_configs_staged"] = other
         except Exception as e:  # noqa: BLE001
             extra["extra_legs_error"] = repr(e)[:400]
+        try:                                                         # SURVEY 8f row N2 beside the contract's line: batched verification through the C ABI
+            nv = 4096
+            rngv = np.random.default_rng(5)
+            vals = rngv.integers(0, 2**63, nv, dtype=np.uint64)
+            eseed = np.frombuffer(rngv.bytes(32 * nv), dtype=np.uint8).copy()
+            vbuf = np.zeros((nv, 298), dtype=np.uint8); vlen = np.zeros(nv, dtype=np.uint32); vst = np.zeros(nv, dtype=np.int32); vok = np.zeros(nv, dtype=np.uint8)
+            _native.check(L.zkp_hip_prove_equality_batch(nv, P(vals), P(vals), P(eseed), P(vbuf), 298, P(vlen), P(vst)), "prove_equality")   # under the key loaded above
+            t_ve = timed(lambda: _native.check(L.zkp_hip_verify_equality_batch(nv, P(vbuf), 298, P(vlen), P(vok)), "verify_equality"), 5)
+            assert vok.all()
+            rv = rngv.integers(0, 2**32, nv, dtype=np.uint64); rmn = np.zeros(nv, dtype=np.uint64); rmx = np.full(nv, 2**32, dtype=np.uint64)
+            rseed = np.frombuffer(rngv.bytes(32 * nv), dtype=np.uint8).copy()
+            rout = np.zeros((nv, 1478), dtype=np.uint8); rlen = np.zeros(nv, dtype=np.uint32); rst = np.zeros(nv, dtype=np.int32)
+            _native.check(L.zkp_hip_prove_range_batch(nv, P(rv), P(rmn), P(rmx), 64, P(rseed), P(rout), 1478, P(rlen), P(rst)), "prove_range")
+            t_vr = timed(lambda: _native.check(L.zkp_hip_verify_range_batch(nv, P(rout), 1478, P(rlen), P(rmn), P(rmx), P(vok)), "verify_range"), 5)
+            assert vok.all()
+            extra["verification_c_abi"] = {"equality_4096": {"envelopes_per_s": nv / t_ve, "ms_per_batch": t_ve * 1e3}, "range_4096": {"envelopes_per_s": nv / t_vr, "ms_per_batch": t_vr * 1e3},
+                                           "note": "host buffers in, verdict bytes out; Groth16 on the Fq2 machine (DESIGN 6d); not part of the contract's value"}
+        except Exception as e:  # noqa: BLE001
+            extra["verification_leg_error"] = repr(e)[:400]
     L.zkp_hip_batch_free(h)
 
     # ------------------------------------------------------------------ BASELINE config 5: ONE 16 384-op batch sharded over the ranks
