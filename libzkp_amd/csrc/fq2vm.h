@@ -14,9 +14,16 @@
 
 namespace zkp { namespace fq2vm {
 
-enum Op : uint32_t { NOP, MUL, SQ, ADD, SUB, MULXI, CONJ, MUL0, MUL1, INV, LDG, STG, LDC, MOV, NEG, LDK, STC, END };
+enum Op : uint32_t { NOP, MUL, SQ, ADD, SUB, MULXI, CONJ, MUL0, MUL1, INV, LDG, STG, LDC, MOV, NEG, LDK, STC, T3M, T3P, END };
 constexpr uint32_t BAR = 0x80u, FQ2_W = 20;
 
+// 3a - 2b and 3a + 2b (the output step of a cyclotomic squaring) as one operation each: limb-wise (3a < 12p with limbs < 2^28; 2b safe for the
+// 8p-borrowing subtraction: limbs < 2^27, value < 8p), one weak reduction per coordinate
+ZKP_HD inline fq fq_t3(const fq& a, const fq& b, bool minus) {
+    const fq a3 = fq_add_l(fq_dbl_l(a), a), b2 = fq_dbl_l(b);
+    return fq_reduce_weak(minus ? fq_sub_k8(a3, b2) : fq_add_l(a3, b2));
+}
+ZKP_HD inline fq2 vm_t3(const fq2& a, const fq2& b, bool minus) { return fq2{fq_t3(a.c0, b.c0, minus), fq_t3(a.c1, b.c1, minus)}; }
 // arithmetic operations: inputs and outputs "safe" in the vocabulary of bn254_fq.h (carried, value < 4p)
 ZKP_HD inline fq2 alu(uint32_t op, const fq2& a, const fq2& b) {
     switch (op) {
@@ -30,10 +37,12 @@ ZKP_HD inline fq2 alu(uint32_t op, const fq2& a, const fq2& b) {
     case MUL1: return fq2_mul_fq(a, b.c1);
     case INV: return f_inv(a);
     case NEG: return f_neg(a);
+    case T3M: return vm_t3(a, b, true);
+    case T3P: return vm_t3(a, b, false);
     default: return a;          // MOV
     }
 }
-ZKP_HD inline bool op_has_b(uint32_t op) { return op == MUL || op == ADD || op == SUB || op == MUL0 || op == MUL1; }
+ZKP_HD inline bool op_has_b(uint32_t op) { return op == MUL || op == ADD || op == SUB || op == MUL0 || op == MUL1 || op == T3M || op == T3P; }
 ZKP_HD inline void fq2_to_words(uint32_t w[FQ2_W], const fq2& a) { for (int k = 0; k < 10; k++) { w[k] = a.c0.v[k]; w[10 + k] = a.c1.v[k]; } }
 ZKP_HD inline fq2 fq2_from_words(const uint32_t w[FQ2_W]) { fq2 a; for (int k = 0; k < 10; k++) { a.c0.v[k] = w[k]; a.c1.v[k] = w[10 + k]; } return a; }
 
@@ -125,6 +134,7 @@ __device__ inline void run_device(const Launch& L, uint32_t* __restrict__ regs) 
             case MUL0: case MUL1: { const fq2 y = ld(b); st(on, d, fq2_mul_fq(ld(a), op == MUL0 ? y.c0 : y.c1)); break; }
             case INV: st(on, d, f_inv(ld(a))); break;
             case NEG: st(on, d, f_neg(ld(a))); break;
+            case T3M: case T3P: st(on, d, vm_t3(ld(a), ld(b), op == T3M)); break;
             case MOV: st(on, d, ld(a)); break;
             // loads from memory: all twenty words are requested before the first is stored (one memory latency per operation, not twenty)
             case LDG: { uint32_t t[FQ2_W]; ZKP_UNROLL for (uint32_t k = 0; k < FQ2_W; k++) t[k] = inb ? io[((size_t)b * FQ2_W + k) * L.n + i] : 0u;

@@ -23,9 +23,9 @@ X = 4965661367192848881
 ATE = 6 * X + 2
 
 # ---------------------------------------------------------------- opcodes (fq2vm.h holds the same list)
-NOP, MUL, SQ, ADD, SUB, MULXI, CONJ, MUL0, MUL1, INV, LDG, STG, LDC, MOV, NEG, LDK, STC, END = range(18)
-OPNAME = ["NOP", "MUL", "SQ", "ADD", "SUB", "MULXI", "CONJ", "MUL0", "MUL1", "INV", "LDG", "STG", "LDC", "MOV", "NEG", "LDK", "STC", "END"]
-COST = {NOP: 0, MUL: 20, SQ: 15, ADD: 4, SUB: 4, MULXI: 7, CONJ: 3, MUL0: 13, MUL1: 13, INV: 700, LDG: 3, STG: 3, LDC: 3, MOV: 2, NEG: 3, LDK: 3, STC: 3}      # ~50 instructions each
+NOP, MUL, SQ, ADD, SUB, MULXI, CONJ, MUL0, MUL1, INV, LDG, STG, LDC, MOV, NEG, LDK, STC, T3M, T3P, END = range(20)
+OPNAME = ["NOP", "MUL", "SQ", "ADD", "SUB", "MULXI", "CONJ", "MUL0", "MUL1", "INV", "LDG", "STG", "LDC", "MOV", "NEG", "LDK", "STC", "T3M", "T3P", "END"]
+COST = {NOP: 0, MUL: 20, SQ: 15, ADD: 4, SUB: 4, MULXI: 7, CONJ: 3, MUL0: 13, MUL1: 13, INV: 700, LDG: 3, STG: 3, LDC: 3, MOV: 2, NEG: 3, LDK: 3, STC: 3, T3M: 5, T3P: 5}      # ~50 instructions each
 BAR = 0x80
 
 
@@ -57,6 +57,8 @@ def apply_op(op, a, b):
     if op == INV: return f2inv(a)
     if op == MOV: return a
     if op == NEG: return (-a[0] % P, -a[1] % P)
+    if op == T3M: return ((3 * a[0] - 2 * b[0]) % P, (3 * a[1] - 2 * b[1]) % P)
+    if op == T3P: return ((3 * a[0] + 2 * b[0]) % P, (3 * a[1] + 2 * b[1]) % P)
     raise ValueError(op)
 
 
@@ -102,6 +104,8 @@ class V:
     def mul0(self, o): return self._bin(MUL0, o)      # self * (c0 of o), an Fq scalar
     def mul1(self, o): return self._bin(MUL1, o)      # self * (c1 of o)
     def inv(self): return self._un(INV)
+    def t3m(self, o): return self._bin(T3M, o)        # 3 self - 2 o (the cyclotomic squaring's output step as one operation)
+    def t3p(self, o): return self._bin(T3P, o)        # 3 self + 2 o
 
 
 def inp(p, name):
@@ -182,8 +186,8 @@ def f4_sq(x, y):
 def f12_cyclo_sq(f):
     (a0, a1, a2), (b0, b1, b2) = f
     t0, t1 = f4_sq(a0, b1); t2, t3 = f4_sq(b0, a2); t4, t5 = f4_sq(a1, b2)
-    m = lambda t, z: t.dbl() + t - z.dbl()
-    q = lambda t, z: t.dbl() + t + z.dbl()
+    m = lambda t, z: t.t3m(z)
+    q = lambda t, z: t.t3p(z)
     return ((m(t0, a0), m(t2, a1), m(t4, a2)), (q(t5.xi(), b0), q(t1, b1), q(t3, b2)))
 
 
@@ -592,7 +596,7 @@ def simulate(streams, regs, gmem, cur=0):
     a register that another wave writes in the same round, and that the two halves of a step do not touch each other's result."""
     K = len(streams)
     pc = [0] * K
-    two = (MUL, ADD, SUB, MUL0, MUL1)
+    two = (MUL, ADD, SUB, MUL0, MUL1, T3M, T3P)
     while pc[0] < len(streams[0]):
         writes, reads = [set() for _ in range(K)], [set() for _ in range(K)]
         new = [dict() for _ in range(K)]
