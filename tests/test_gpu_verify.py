@@ -249,6 +249,28 @@ def test_groth16_verification(hip):
     assert z.verify_proofs_parallel([(proofs[1], "equality"), (mp[1], "membership"), (bad[1], "equality"), (proofs[2], "membership")]) == [True, True, False, False]
 
 
+def _f2_sqrt(bn, a):
+    """square root in Fq2 (p = 3 mod 4), None for a non-residue"""
+    def f2pow(b, e):
+        r = (1, 0)
+        while e:
+            if e & 1:
+                r = bn.f2_mul(r, b)
+            b = bn.f2_mul(b, b); e >>= 1
+        return r
+    if a == (0, 0):
+        return (0, 0)
+    a1 = f2pow(a, (bn.P - 3) // 4)
+    alpha = bn.f2_mul(bn.f2_mul(a1, a1), a)
+    a0 = bn.f2_mul(f2pow(alpha, bn.P), alpha)
+    if a0 == (bn.P - 1, 0):
+        return None
+    x0 = bn.f2_mul(a1, a)
+    if alpha == (bn.P - 1, 0):
+        return bn.f2_mul((0, 1), x0)
+    return bn.f2_mul(f2pow(bn.f2_add((1, 0), alpha), (bn.P - 1) // 2), x0)
+
+
 _G16_PATHS_CHILD = r"""
 import json, os, sys
 import numpy as np
@@ -293,6 +315,21 @@ def test_groth16_machine_and_lane_per_chain_paths_agree(hip, tmp_path):
     for off, size in ((10, 64), (74, 128), (202, 64)):         # A, B, C replaced by the point at infinity
         b = bytearray(proofs[1]); b[off:off + size] = (bytes(size - 1) + b"\x40"); special.append(bytes(b))
     special += [bytes(bytearray(proofs[2][:10]) + inf1 + bytearray(proofs[2][74:]))] * 5
+    # B moved out of G2 by a point of the twist's cofactor part (on the curve, canonical, finite): only the subgroup check rejects it
+    from oracle.py import bn254 as bn
+    import random as _random
+    rr = _random.Random(9)
+    while True:
+        x = (rr.randrange(bn.P), rr.randrange(bn.P))
+        y2 = bn.f2_add(bn.f2_mul(bn.f2_sq(x), x), bn.B2)
+        y = _f2_sqrt(bn, y2)
+        if y is not None:
+            break
+    cof = bn.G2C.mul_pt((x, y), bn.R, reduce=False)
+    okb, bpt = bn.de_g2(proofs[3][74:202])
+    assert okb and cof is not None and bn.G2C.is_on_curve(cof)
+    moved = bytearray(proofs[3]); moved[74:202] = bn.ser_g2(bn.G2C.add_pts(bpt, cof))
+    blobs.insert(153, bytes(moved))                             # index 153: checked against the oracle below
     blobs += special                                            # the last eight: present only in the second call of the child
     sets = [[int(x) for x in rng.choice(2**32, 7, replace=False)] for _ in range(20)]
     mp = z.prove_membership_batch([s[i % 7] for i, s in enumerate(sets)], sets)
@@ -307,7 +344,7 @@ def test_groth16_machine_and_lane_per_chain_paths_agree(hip, tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     lane = json.loads(out.stdout.strip().splitlines()[-1])
     assert got == lane
-    assert got[0][:70] == [True] * 70 and got[0][150:153] == [True] * 3 and got[2][:10] == [True] * 10
+    assert got[0][:70] == [True] * 70 and got[0][150:153] == [True] * 3 and got[0][153] is False and got[2][:10] == [True] * 10
     assert got[1][:len(got[0])] == got[0] and not any(got[1][-8:])
-    for i in list(range(66, 78)) + list(range(150, 161)):
+    for i in list(range(66, 78)) + list(range(150, 162)):
         assert got[1][i] == g.verify_equality_with_commitment(blobs[i], blobs[i][266:], SS), i

@@ -103,6 +103,23 @@ while time.time() < t_end:
         if not all(api._verify_snark_envelopes(0, ep)):
             print("EQUALITY VERIFY FAIL it", it); sys.exit(1)
         counts["equality"] += k
+        # tampered Groth16 envelopes: one to three flipped bits, none of them a sign flag of an uncompressed point (ark ignores those):
+        # the pairing check on the Fq2 machine must reject every one
+        sign_bits = {(73, 7), (201, 7), (265, 7)}
+        bad = []
+        for e in ep:
+            t = bytearray(e)
+            for _ in range(int(rng.integers(1, 4))):
+                while True:
+                    pos, bit = int(rng.integers(0, 298)), int(rng.integers(0, 8))
+                    if (pos, bit) not in sign_bits: break
+                t[pos] ^= 1 << bit
+            if bytes(t) != e: bad.append(bytes(t))
+        acc = api._verify_snark_envelopes(0, bad)
+        if any(acc):
+            i = acc.index(True)
+            print("TAMPERED EQUALITY ENVELOPE ACCEPTED it", it, "\noriginal:", ep[min(i, len(ep) - 1)].hex(), "\ntampered:", bad[i].hex()); sys.exit(1)
+        counts["equality_tampered"] = counts.get("equality_tampered", 0) + len(bad)
         sets = [[int(x) for x in rng.choice(2**40, int(rng.integers(1, 65)), replace=False)] for _ in range(min(k, 20))]
         mp = z.prove_membership_batch([s[int(rng.integers(0, len(s)))] for s in sets], sets)
         if not all(z.verify_membership_batch(mp, sets)):
