@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(64) k_g16_vm_verdict(uint32_t n, const uint32_
 size_t g16_vm_scratch_bytes(uint32_t n) { return (size_t)n * ((size_t)fq2vm::N_SLOTS * fq2vm::FQ2_W * 4 + sizeof(G16Pairs) + 1) + 512; }
 G16Pairs* g16_vm_pairs(void* d_scratch, uint32_t n) { return reinterpret_cast<G16Pairs*>(reinterpret_cast<uint32_t*>(d_scratch) + (size_t)fq2vm::N_SLOTS * fq2vm::FQ2_W * n); }
 
-int g16_vm_upload(G16VmTables& T) {
+int g16_vm_upload(G16VmTables& T) {          // (g16_vm_free is declared in g16_verify_launch.h)
     auto up = [](const void* src, size_t bytes, const void** dst) -> int {
         void* p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) return -1;
@@ -74,8 +74,9 @@ int g16_vm_upload(G16VmTables& T) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fq2vm), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (auto& q : T.side) if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) rc = -1;
     for (auto& e : T.ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = -1;
-    T.ready = rc == 0;
-    return rc;
+    if (rc) { g16_vm_free(T); return -1; }          // a partial upload leaves nothing behind
+    T.ready = true;
+    return 0;
 }
 void g16_vm_free(G16VmTables& T) {
     if (T.code) (void)hipFree((void*)T.code);
