@@ -787,8 +787,8 @@ def f2sqrt(a):
 
 NREG = {"M": 46, "S": 16, "F": 62, "B": 46, "L": 24}
 # slots of a wave (= operations of one opcode it runs at a time): two = 32 envelopes per workgroup.  (Four slots = 16 envelopes per workgroup were
-# scheduled for the final exponentiation -- 256 workgroups instead of 128 per 4096 envelopes, 124 registers: the estimate drops by 18 %, its
-# squarings are bound by their dependency chain; the interpreter has no four-slot form.)
+# built for the final exponentiation -- 256 workgroups instead of 128 per 4096 envelopes, 80 registers: estimate -20 %, measured 3.57 against
+# 3.39 ms and less throughput on large batches; the interpreter keeps the two-slot form only.)
 SLOTS = {"M": 2, "S": 2, "F": 2, "B": 2, "L": 2}       # what the LDS holds with 32 envelopes per workgroup: 46 x 80 bytes x 32 (Miller) + 16 x 80 x 32 (subgroup) on one CU; 62 x 80 x 32 (finish)
 
 
