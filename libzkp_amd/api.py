@@ -457,12 +457,7 @@ def _verify_snark_envelopes(kind, blobs):
     if n == 0:
         return []
     _ensure_key(kind)
-    stride = min(4096, max(16, max(len(b) for b in blobs)))
-    buf = np.zeros((n, stride), dtype=np.uint8)
-    lens = np.zeros(n, dtype=np.uint32)
-    for i, b in enumerate(blobs):
-        lens[i] = len(b)
-        buf[i, : min(len(b), stride)] = np.frombuffer(b[:stride], dtype=np.uint8)
+    buf, lens, stride = _rows(blobs, 4096)
     ok = np.zeros(n, dtype=np.uint8)
     fn = _native.lib().zkp_hip_verify_equality_batch if kind == 0 else _native.lib().zkp_hip_verify_membership_batch
     _native.check(fn(n, _P(buf), stride, _P(lens), _P(ok)), "zkp_hip_verify_%s_batch" % ("equality" if kind == 0 else "membership"))
@@ -518,12 +513,7 @@ def verify_consistency_batch(proofs):
     if n == 0:
         return []
     blobs = [bytes(p) for p in proofs]
-    stride = min(1 << 20, max(16, max(len(b) for b in blobs)))
-    buf = np.zeros((n, stride), dtype=np.uint8)
-    lens = np.zeros(n, dtype=np.uint32)
-    for i, b in enumerate(blobs):
-        lens[i] = len(b)
-        buf[i, : min(len(b), stride)] = np.frombuffer(b[:stride], dtype=np.uint8)
+    buf, lens, stride = _rows(blobs, 1 << 20)
     ok = np.zeros(n, dtype=np.uint8)
     _native.check(_native.lib().zkp_hip_verify_consistency_batch(n, _P(buf), stride, _P(lens), _P(ok)), "zkp_hip_verify_consistency_batch")
     return [bool(x) for x in ok]
@@ -542,12 +532,7 @@ def verify_improvement_batch(proofs, olds):
         return []
     ov = np.array([_check_u64("old", x) for x in olds], dtype=np.uint64)
     blobs = [bytes(p) for p in proofs]
-    stride = min(8192, max(16, max(len(b) for b in blobs)))
-    buf = np.zeros((n, stride), dtype=np.uint8)
-    lens = np.zeros(n, dtype=np.uint32)
-    for i, b in enumerate(blobs):
-        lens[i] = len(b)
-        buf[i, : min(len(b), stride)] = np.frombuffer(b[:stride], dtype=np.uint8)
+    buf, lens, stride = _rows(blobs, 8192)
     ok = np.zeros(n, dtype=np.uint8)
     _native.check(_native.lib().zkp_hip_verify_improvement_batch(n, _P(buf), stride, _P(lens), _P(ov), _P(ok)), "zkp_hip_verify_improvement_batch")
     return [bool(x) for x in ok]
