@@ -348,3 +348,25 @@ def test_groth16_machine_and_lane_per_chain_paths_agree(hip, tmp_path):
     assert got[1][:len(got[0])] == got[0] and not any(got[1][-8:])
     for i in list(range(66, 78)) + list(range(150, 162)):
         assert got[1][i] == g.verify_equality_with_commitment(blobs[i], blobs[i][266:], SS), i
+
+
+def test_groth16_machine_batch_sizes(hip):
+    """Batch sizes around the machine's 32-envelope workgroups (1, 2, 31, 33, 65, 95): every verdict right, valid and tampered envelopes
+    interleaved (lanes past the end of a batch must neither be read nor written)."""
+    import os
+    import libzkp_amd as z
+    import libzkp_amd.api as api
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")):
+        api.install_proving_key(kind, open(os.path.join(gold, name), "rb").read())
+    rng = np.random.default_rng(123)
+    vals = [int(x) for x in rng.integers(0, 2**63, 95, dtype=np.uint64)]
+    proofs = z.prove_equality_batch(vals, vals)
+    for n in (1, 2, 31, 33, 65, 95):
+        blobs, want = [], []
+        for i in range(n):
+            if i % 3 == 1:
+                b = bytearray(proofs[i]); b[20 + (7 * i) % 250] ^= 0x10; blobs.append(bytes(b)); want.append(False)
+            else:
+                blobs.append(proofs[i]); want.append(True)
+        assert api._verify_snark_envelopes(0, blobs) == want, n
