@@ -24,19 +24,20 @@ __device__ inline fq2 vm_get(const uint32_t* io, uint32_t n, uint32_t i, uint32_
     return x;
 }
 // flags: 0 = a point fails to parse (verdict: reject), 1 = the generic case (all three pairs present, B finite), 2 = special
-__global__ void __launch_bounds__(64) k_g16_pairs_vm(int kind, const uint8_t* in, uint64_t stride, const uint32_t* len, uint32_t n, G16Vk vk, G16Pairs* pairs, uint32_t* io, uint8_t* flags) {
+__global__ void __launch_bounds__(64) k_g16_pairs_vm(int kind, const uint8_t* in, uint64_t stride, const uint32_t* len, uint32_t n, G16Vk vk, uint32_t* io, uint8_t* flags) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const uint32_t l = len[i] <= stride ? len[i] : 0u;
     const uint8_t* env = in + (uint64_t)i * stride;
     G16Pairs o;
-    const bool v = kind == G16_EQUALITY ? g16_equality_pairs(vk, env, l, o) : g16_membership_pairs(vk, env, l, o);
+    g1_jac L;                                             // the public-input point stays Jacobian: chain B takes it projectively (g16_vm_pair1)
+    const bool v = kind == G16_EQUALITY ? g16_equality_pairs(vk, env, l, o, &L) : g16_membership_pairs(vk, env, l, o, &L);
     const bool generic = v && o.present == 15u;
     flags[i] = !v ? 0 : generic ? 1 : 2;
-    if (v) pairs[i] = o;
     for (uint32_t j = 0; j < 3; j++) {
         fq2 qx, qy, p;
-        if (generic) { qx = o.Q[j].x; qy = o.Q[j].y; p = fq2{o.P[j].x, o.P[j].y}; }
+        if (generic && j == 1) { g16_vm_pair1(L, p, qx); f_set_zero(qy); }          // chain B reads gamma's lines from the key's table: the Q.x slot carries Z^3
+        else if (generic) { qx = o.Q[j].x; qy = o.Q[j].y; p = fq2{o.P[j].x, o.P[j].y}; }
         else { f_set_zero(qx); f_set_zero(qy); f_set_zero(p); }
         vm_put(io, n, i, fq2vm::PAIR_SLOTS * j + fq2vm::SLOT_QX, qx);
         vm_put(io, n, i, fq2vm::PAIR_SLOTS * j + fq2vm::SLOT_QY, qy);
@@ -54,8 +55,7 @@ __global__ void __launch_bounds__(64) k_g16_vm_verdict(uint32_t n, const uint32_
     ok[i] = good ? 1 : 0;
 }
 
-size_t g16_vm_scratch_bytes(uint32_t n) { return (size_t)n * ((size_t)fq2vm::N_SLOTS * fq2vm::FQ2_W * 4 + sizeof(G16Pairs) + 1) + 512; }
-G16Pairs* g16_vm_pairs(void* d_scratch, uint32_t n) { return reinterpret_cast<G16Pairs*>(reinterpret_cast<uint32_t*>(d_scratch) + (size_t)fq2vm::N_SLOTS * fq2vm::FQ2_W * n); }
+size_t g16_vm_scratch_bytes(uint32_t n) { return (size_t)n * ((size_t)fq2vm::N_SLOTS * fq2vm::FQ2_W * 4 + 1) + 512; }          // the slot buffer, then one flag byte per envelope
 
 int g16_vm_upload(G16VmTables& T) {          // (g16_vm_free is declared in g16_verify_launch.h)
     auto up = [](const void* src, size_t bytes, const void** dst) -> int {
@@ -116,10 +116,9 @@ void g16_launch_verify_vm(int kind, const uint8_t* d_in, uint64_t stride, const 
                           const uint32_t* d_lines, void* d_scratch, uint8_t* d_ok, uint32_t* d_special, hipStream_t st) {
     if (!n) return;
     uint32_t* io = reinterpret_cast<uint32_t*>(d_scratch);
-    G16Pairs* pairs = g16_vm_pairs(d_scratch, n);
-    uint8_t* flags = reinterpret_cast<uint8_t*>(pairs + n);
+    uint8_t* flags = reinterpret_cast<uint8_t*>(io + (size_t)fq2vm::N_SLOTS * fq2vm::FQ2_W * n);
     const uint32_t nb = (n + 63) / 64;
-    k_g16_pairs_vm<<<nb, 64, 0, st>>>(kind, d_in, stride, d_len, n, vk, pairs, io, flags);
+    k_g16_pairs_vm<<<nb, 64, 0, st>>>(kind, d_in, stride, d_len, n, vk, io, flags);
     const uint32_t K = 4, ng = (n + fq2vm::G - 1) / fq2vm::G;
     const size_t pair_words = (size_t)fq2vm::PAIR_SLOTS * fq2vm::FQ2_W * n;
     // chain: 0 = A, 1 = subgroup, 2 = finish, 3 = B (the index of its script in T.script and of its register count in REGS_K4)

@@ -111,7 +111,8 @@ ZKP_HD_NOINLINE inline g1_jac g16_ic_mul(const G16Vk& vk, uint32_t i, const uint
 // bit 3: Q[0] holds a finite B whose subgroup membership is still to be checked (g16_b_in_subgroup).
 struct G16Pairs { g1_aff P[3]; g2_aff Q[3]; uint32_t present; };
 // proof bytes (A || B || C) and the accumulated public-input point L (Jacobian); false: a point fails to parse
-ZKP_HD_NOINLINE inline bool g16_pairs(const G16Vk& vk, const uint8_t proof[256], const g1_jac& L, G16Pairs& o) {
+// (Lout != nullptr: the Fq2 machine's form -- L stays Jacobian in *Lout, no inversion; P[1] is left unset, bit 1 of `present` says L is finite)
+ZKP_HD_NOINLINE inline bool g16_pairs(const G16Vk& vk, const uint8_t proof[256], const g1_jac& L, G16Pairs& o, g1_jac* Lout = nullptr) {
     g1_aff A, C; g2_aff B;
     const int ra = g1_from_ark(A, proof), rb = g2_from_ark(B, proof + 64), rc = g1_from_ark(C, proof + 192);
     o.present = 0;
@@ -119,9 +120,17 @@ ZKP_HD_NOINLINE inline bool g16_pairs(const G16Vk& vk, const uint8_t proof[256],
     if (rb == 1) { o.Q[0] = B; o.present |= 8u; }
     if (ra == 1 && rb == 1) { o.P[0] = A; o.present |= 1u; }
     g1_aff La;
-    if (jac_to_aff(La, L)) { o.P[1] = aff_neg(La); o.Q[1] = vk.gamma; o.present |= 2u; }
+    if (Lout) { *Lout = L; if (!jac_is_inf(L)) { o.Q[1] = vk.gamma; o.present |= 2u; } }
+    else if (jac_to_aff(La, L)) { o.P[1] = aff_neg(La); o.Q[1] = vk.gamma; o.present |= 2u; }
     if (rc == 1) { o.P[2] = aff_neg(C); o.Q[2] = vk.delta; o.present |= 4u; }
     return true;
+}
+// The machine's inputs for the pair (gamma, -L) with L = (X, Y, Z) Jacobian: chain B evaluates a line (a yp, b xp, c) at xp = X / Z^2,
+// yp = -Y / Z^3 scaled by Z^3 -- a factor in Fq, which the final exponentiation removes -- as (a (-Y), b (X Z), c Z^3): p = (X Z, -Y), pz = (Z^3, 0)
+ZKP_HD inline void g16_vm_pair1(const g1_jac& L, fq2& p, fq2& pz) {
+    const fq zz = fq_reduce_weak(fq_sq(L.Z));
+    p = fq2{fq_reduce_weak(fq_mul(L.X, L.Z)), fq_neg(L.Y)};
+    pz = fq2{fq_reduce_weak(fq_mul(zz, L.Z)), fq_zero()};
 }
 ZKP_HD inline bool g16_b_in_subgroup(const G16Pairs& o) { return (o.present & 8u) == 0 || g2_in_subgroup(o.Q[0]); }
 ZKP_HD inline fq12 g16_pair_miller(const G16Pairs& o, uint32_t j) { return (o.present >> j) & 1u ? miller_loop(o.Q[j], o.P[j]) : fq12_one(); }
@@ -129,18 +138,18 @@ ZKP_HD_NOINLINE inline bool g16_finish(const G16Vk& vk, const fq12& f0, const fq
     return fq12_is_one(final_exponentiation_chain(fq12_mul(fq12_mul(vk.ml_alpha_beta, f0), fq12_mul(f1, f2))));
 }
 // equality envelope (scheme 2, 298 bytes): public input = the embedded 32-byte commitment as an integer < r
-ZKP_HD_NOINLINE inline bool g16_equality_pairs(const G16Vk& vk, const uint8_t* env, uint32_t len, G16Pairs& o) {
+ZKP_HD_NOINLINE inline bool g16_equality_pairs(const G16Vk& vk, const uint8_t* env, uint32_t len, G16Pairs& o, g1_jac* Lout = nullptr) {
     o.present = 0;
     if (len != 298 || env[0] != 2 || env[1] != 2 || vk.n_ic != 2) return false;
     if (ld_u32_le(env + 2) != 256 || ld_u32_le(env + 6) != 32) return false;
     uint32_t c[8]; ld_le_words(c, env + 266);
     if (!fr_raw_lt_r(c)) return false;
     const g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), g16_ic_mul(vk, 1, c, G16V_NWIN));
-    return g16_pairs(vk, env + 10, L, o);
+    return g16_pairs(vk, env + 10, L, o, Lout);
 }
 // membership envelope (scheme 4): payload = u32 n || n x u64 set || 256-byte proof; public inputs =
 // commitment, 64 set slots (zero padded), 64 is_real flags (snark.rs:482-492)
-ZKP_HD_NOINLINE inline bool g16_membership_pairs(const G16Vk& vk, const uint8_t* env, uint32_t len, G16Pairs& o) {
+ZKP_HD_NOINLINE inline bool g16_membership_pairs(const G16Vk& vk, const uint8_t* env, uint32_t len, G16Pairs& o, g1_jac* Lout = nullptr) {
     o.present = 0;
     if (len < 10 + 4 + 256 + 32 || env[0] != 2 || env[1] != 4 || vk.n_ic != 2 + 2 * G16_MAX_SET) return false;
     const uint32_t plen = ld_u32_le(env + 2), clen = ld_u32_le(env + 6);
@@ -156,7 +165,7 @@ ZKP_HD_NOINLINE inline bool g16_membership_pairs(const G16Vk& vk, const uint8_t*
         if (v) L = jac_add(L, vk.ic_table ? g16_ic_mul(vk, 2 + i, vw, G16V_NWIN_U64) : g1_mul_u64(ld_ic(vk, 2 + i), v));
         L = jac_madd(L, ld_ic(vk, 2 + G16_MAX_SET + i));            // is_real = 1
     }
-    return g16_pairs(vk, env + 14 + 8 * n, L, o);
+    return g16_pairs(vk, env + 14 + 8 * n, L, o, Lout);
 }
 // one envelope start to finish in one thread (what the three GPU kernels compute between them; used by the host emulation)
 ZKP_HD inline bool g16_verify_envelope(int kind, const G16Vk& vk, const uint8_t* env, uint32_t len) {

@@ -21,7 +21,6 @@ void g16_vm_free(G16VmTables& T);
 // per key: the machine's Miller value of (beta, -alpha) and the line table of gamma and delta (host computation through the same tables)
 void g16_vm_key_constants(const zkp::g2_aff& beta, const zkp::g1_aff& neg_alpha, const zkp::g2_aff& gamma, const zkp::g2_aff& delta, uint32_t ml[6 * 20], std::vector<uint32_t>& lines);
 size_t g16_vm_scratch_bytes(uint32_t n);
-zkp::G16Pairs* g16_vm_pairs(void* d_scratch, uint32_t n);
 // verdicts of the generic envelopes in d_ok (0 for the others); *d_special (zeroed by the caller) counts the envelopes with a point at infinity in
 // the proof, whose verdicts only g16_launch_verify gives
 void g16_launch_verify_vm(int kind, const uint8_t* d_in, uint64_t stride, const uint32_t* d_len, uint32_t n, const zkp::G16Vk& vk, const G16VmTables& T, const uint32_t* d_kconst,

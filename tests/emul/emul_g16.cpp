@@ -98,7 +98,8 @@ static int verify_with(int mode, int kind, const uint8_t* env, uint32_t len, con
     }
     namespace vm = fq2vm;
     G16Pairs o;
-    if (!(kind == G16_EQUALITY ? g16_equality_pairs(vk, env, len, o) : g16_membership_pairs(vk, env, len, o))) return 0;
+    g1_jac Lj;                                           // as k_g16_pairs_vm: the public-input point stays Jacobian
+    if (!(kind == G16_EQUALITY ? g16_equality_pairs(vk, env, len, o, &Lj) : g16_membership_pairs(vk, env, len, o, &Lj))) return 0;
     if (o.present != 15u) return 2;
     const vm::Tables T = vm::Tables{vm::CODE_K4, vm::OFF_K4, 4, &vm::CONSTS[0][0]};
     const uint32_t* regs = vm::REGS_K4;
@@ -122,7 +123,10 @@ static int verify_with(int mode, int kind, const uint8_t* env, uint32_t len, con
                 for (uint32_t k = 0; k < 3 * vm::FQ2_W; k++) lines[((size_t)6 * st + 3 * j) * vm::FQ2_W + k] = io3[((size_t)vm::LINE_SLOT0 + 6 * st) * vm::FQ2_W + k];
         }
     }
-    for (uint32_t j = 0; j < 3; j++) { put(io, vm::PAIR_SLOTS * j + vm::SLOT_QX, o.Q[j].x); put(io, vm::PAIR_SLOTS * j + vm::SLOT_QY, o.Q[j].y); put(io, vm::PAIR_SLOTS * j + vm::SLOT_P, fq2{o.P[j].x, o.P[j].y}); }
+    for (uint32_t j = 0; j < 3; j++) {
+        if (j == 1) { fq2 p1, p1z; g16_vm_pair1(Lj, p1, p1z); put(io, vm::PAIR_SLOTS + vm::SLOT_P, p1); put(io, vm::PAIR_SLOTS + vm::SLOT_QX, p1z); continue; }
+        put(io, vm::PAIR_SLOTS * j + vm::SLOT_QX, o.Q[j].x); put(io, vm::PAIR_SLOTS * j + vm::SLOT_QY, o.Q[j].y); put(io, vm::PAIR_SLOTS * j + vm::SLOT_P, fq2{o.P[j].x, o.P[j].y});
+    }
     { vm::Launch L{T, vm::SCRIPT_MILLER, (uint32_t)(sizeof(vm::SCRIPT_MILLER) / 2), 1, io.data(), 0, nullptr}; vm::run_host(L, 0, regs[0]); }
     { vm::Launch L{T, vm::SCRIPT_MILLER_B, (uint32_t)(sizeof(vm::SCRIPT_MILLER_B) / 2), 1, io.data() + (size_t)vm::PAIR_SLOTS * vm::FQ2_W, 0, lines.data()}; vm::run_host(L, 0, regs[3]); }
     { vm::Launch L{T, vm::SCRIPT_SUBGROUP, (uint32_t)(sizeof(vm::SCRIPT_SUBGROUP) / 2), 1, io.data(), 0, nullptr}; vm::run_host(L, 0, regs[1]); }

@@ -281,22 +281,26 @@ def build_programs():
     # ---- chain B: the two pairs whose G2 point belongs to the key (gamma, delta) in one chain, on line coefficients computed when the
     # key is loaded (chain L below): no point arithmetic, one squaring of f for both.  The table is read through the cursor (LDK).
     BP = F_NAMES + ["P1", "P2"]
-    def table_lines(p, p1, p2, base): return at_point(tuple(V(p, p.emit(LDK, imm=base + k)) for k in range(3)), p1), at_point(tuple(V(p, p.emit(LDK, imm=base + 3 + k)) for k in range(3)), p2)
+    # the public-input point of pair 1 comes in Jacobian form (no inversion in the parsing kernel): P1 = (X Z, -Y) and P1Z = (Z^3, .) evaluate its
+    # line scaled by Z^3, a factor in Fq that the final exponentiation removes (g16_verify.h g16_vm_pair1)
+    def table_lines(p, p1, p1z, p2, base):
+        r1 = tuple(V(p, p.emit(LDK, imm=base + k)) for k in range(3))
+        return (r1[0].mul1(p1), r1[1].mul0(p1), r1[2].mul0(p1z)), at_point(tuple(V(p, p.emit(LDK, imm=base + 3 + k)) for k in range(3)), p2)
     p = prog("B_INIT")
-    out(p, "P1", ldg(p, SLOT_P)); out(p, "P2", ldg(p, PAIR_SLOTS + SLOT_P))
+    out(p, "P1", ldg(p, SLOT_P)); out(p, "P1Z", ldg(p, SLOT_QX)); out(p, "P2", ldg(p, PAIR_SLOTS + SLOT_P))
     one, zero = const(p, (1, 0)), const(p, (0, 0))
     out12(p, F_NAMES, from_coeffs([one] + [V(p, p.emit(MOV, zero.r)) for _ in range(5)]))
     p = prog("B_DBL")
-    f, p1, p2 = in12(p, F_NAMES), inp(p, "P1"), inp(p, "P2")
-    l1, l2 = table_lines(p, p1, p2, 0)
+    f, p1, p1z, p2 = in12(p, F_NAMES), inp(p, "P1"), inp(p, "P1Z"), inp(p, "P2")
+    l1, l2 = table_lines(p, p1, p1z, p2, 0)
     out12(p, F_NAMES, f12_mul_ll(f12_sq(f), line_mul(l1, l2)))
     p = prog("B_ADD")
-    f, p1, p2 = in12(p, F_NAMES), inp(p, "P1"), inp(p, "P2")
-    l1, l2 = table_lines(p, p1, p2, 0)
+    f, p1, p1z, p2 = in12(p, F_NAMES), inp(p, "P1"), inp(p, "P1Z"), inp(p, "P2")
+    l1, l2 = table_lines(p, p1, p1z, p2, 0)
     out12(p, F_NAMES, f12_mul_ll(f, line_mul(l1, l2)))
     p = prog("B_FROB")
-    f, p1, p2 = in12(p, F_NAMES), inp(p, "P1"), inp(p, "P2")
-    l1, l2 = table_lines(p, p1, p2, 0); l3, l4 = table_lines(p, p1, p2, 6)
+    f, p1, p1z, p2 = in12(p, F_NAMES), inp(p, "P1"), inp(p, "P1Z"), inp(p, "P2")
+    l1, l2 = table_lines(p, p1, p1z, p2, 0); l3, l4 = table_lines(p, p1, p1z, p2, 6)
     f = f12_mul_ll(f12_mul_ll(f, line_mul(l1, l2)), line_mul(l3, l4))
     for k, v in enumerate(coeffs(f)): stg(p, v, SLOT_F0 + k)
     # ---- chain L (once per key and G2 point, on the host): the same steps as chain A without the G1 point, storing the raw line
@@ -638,7 +642,7 @@ def pin_maps():
     sub = {n: i for i, n in enumerate(["TX", "TY", "TZ", "QX", "QY"])}
     names = ["a%d" % i for i in range(6)] + ["b%d" % i for i in range(6)]
     fin = {n: i for i, n in enumerate(names)}
-    cb = {n: i for i, n in enumerate(F_NAMES + ["P1", "P2"])}
+    cb = {n: i for i, n in enumerate(F_NAMES + ["P1", "P1Z", "P2"])}
     return {"M": miller, "S": sub, "F": fin, "B": cb, "L": sub}
 
 
@@ -720,8 +724,12 @@ def check():
             for k in range(N_LINE_SLOTS // 6):
                 for c in range(3): tab[("k", 6 * k + 3 * j + c)] = g[LINE_SLOT0 + 6 * k + c]
         return tab
+    def proj(p1):           # an affine G1 point as the parsing kernel hands it over: a random Jacobian form (X, Y, Z), packed (X Z, Y), (Z^3, 0)
+        zz = rnd.randrange(1, P)
+        Xj, Yj = p1[0] * zz * zz % P, p1[1] * zz * zz * zz % P
+        return (Xj * zz % P, Yj), (zz * zz * zz % P, 0)
     def miller_b(tab, p1, p2):
-        g = dict(tab); g[SLOT_P] = p1; g[PAIR_SLOTS + SLOT_P] = p2
+        g = dict(tab); g[SLOT_P], g[SLOT_QX] = proj(p1); g[PAIR_SLOTS + SLOT_P] = p2
         run_script(progs, sc["miller_b"], g)
         return [g[SLOT_F0 + k] for k in range(6)]
     a, b = rnd.randrange(1, R), rnd.randrange(1, R)
@@ -755,7 +763,7 @@ def check():
     # scheduled + allocated programs against the traced ones, on the same inputs
     for K, nreg in ((1, {"M": 64, "S": 32, "F": 96, "B": 64, "L": 32}), (4, NREG)):
         progs2, comp = compile_all(K, nreg, verbose=True, search=K > 1)
-        gb = dict(tab); gb[SLOT_P] = aP; gb[PAIR_SLOTS + SLOT_P] = O.G1C.neg_pt(abP)
+        gb = dict(tab); gb[SLOT_P], gb[SLOT_QX] = proj(aP); gb[PAIR_SLOTS + SLOT_P] = O.G1C.neg_pt(abP)
         for chain, gm in (("miller", {SLOT_QX: bQ[0], SLOT_QY: bQ[1], SLOT_P: aP}), ("subgroup", {SLOT_QX: bQ[0], SLOT_QY: bQ[1]}),
                           ("lines", {SLOT_QX: bQ[0], SLOT_QY: bQ[1]}), ("miller_b", gb),
                           ("finish", {(SLOT_FIN(j, k) if j < 2 else ("k", k)): [f1, f2, one12][j][k] for j in range(3) for k in range(6)})):
