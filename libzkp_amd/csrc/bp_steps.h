@@ -178,6 +178,7 @@ struct MsmView {
                                  // fixed offset point so the unchecked mixed addition never sees infinity); nullptr = identity
     uint32_t nwin = 0, nent = 0, digw = 0;      // k_msm_gather only: shape of the table behind `table` (windows per point, entries per
                                                 // window, digit words per scalar) -- a run-time property of the loaded Groth16 key
+    uint32_t slot_ent = 0, uneven = 0;          // entries of one point's block; uneven radix (g16_steps.h): window 17 starts one nent later
 };
 ZKP_HD inline void msm_chunk_ref(const MsmView& m, uint32_t chunk, uint32_t row) {
     ge acc = ge_identity();

@@ -102,10 +102,12 @@ __global__ void __launch_bounds__(TW) k_mimc_commit(const uint64_t* values, uint
 constexpr uint32_t G16_TABLE_SEG = 512;
 template <class F, uint32_t AFF_W>
 __global__ void __launch_bounds__(TW, 2) k_g16_build_table(const uint32_t* bases, uint32_t nslots, uint32_t* table, uint32_t fmt9, G16Radix rx) {
-    const uint32_t seg_len = rx.nent < G16_TABLE_SEG ? rx.nent : G16_TABLE_SEG, nseg = rx.nent / seg_len;
+    const uint32_t seg_len = rx.nent < G16_TABLE_SEG ? rx.nent : G16_TABLE_SEG, nseg = rx.nent / seg_len, slot_seg = rx.slot_ent / seg_len;
     const uint32_t t = blockIdx.x * TW + threadIdx.x;
-    if (t >= nslots * rx.nwin * nseg) return;
-    const uint32_t seg = t % nseg, win = (t / nseg) % rx.nwin, slot = t / (nseg * rx.nwin);
+    if (t >= nslots * slot_seg) return;
+    const uint32_t slot = t / slot_seg, sg = t % slot_seg;          // segment within the point's block -> (window, segment of the window)
+    uint32_t win = sg / nseg, seg = sg % nseg;
+    if (rx.uneven && sg >= 16u * nseg) { win = sg < 18u * nseg ? 16u : 17u; seg = sg - (win == 16u ? 16u : 18u) * nseg; }
     constexpr uint32_t FW = AFF_W / 2, BATCH = 8;
     Aff<F> base;
     {
@@ -114,7 +116,7 @@ __global__ void __launch_bounds__(TW, 2) k_g16_build_table(const uint32_t* bases
         for (uint32_t k = 0; k < FW; k++) { bx[k] = b[k]; by[k] = b[FW + k]; }
     }
     Jac<F> q = jac_from_aff(base);
-    for (uint32_t i = 0; i < rx.wbits * win; i++) q = jac_dbl(q);
+    for (uint32_t i = 0; i < g16_win_bit(rx, win); i++) q = jac_dbl(q);
     // acc = (seg * seg_len + 1) q: binary ladder over the segment's first index (at most wbits - 1 bits)
     Jac<F> acc = q;
     {
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(TW, 2) k_g16_build_table(const uint32_t* bases
     }
     constexpr uint32_t NC = AFF_W / 10;                      // Fq coordinates per entry
     const uint32_t OW = fmt9 ? 8 * NC : AFF_W;             // words per stored entry
-    uint32_t* dst = table + (((size_t)slot * rx.nwin + win) * rx.nent + (size_t)seg * seg_len) * OW;
+    uint32_t* dst = table + ((size_t)slot * rx.slot_ent + g16_win_off(rx, win) + (size_t)seg * seg_len) * OW;
     for (uint32_t e0 = 0; e0 < seg_len; e0 += BATCH) {
         Jac<F> pts[BATCH]; F zp[BATCH];
         for (uint32_t k = 0; k < BATCH; k++) {
@@ -188,7 +190,7 @@ void g16_launch_mimc(const uint64_t* values, uint32_t n, const uint32_t* mimc_c,
 // g16_verify.h)
 void g16_launch_build_table(bool g2, const uint32_t* bases, uint32_t nslots, uint32_t* table, hipStream_t st, bool msm_form, const G16Radix& rx) {
     const uint32_t seg_len = rx.nent < G16_TABLE_SEG ? rx.nent : G16_TABLE_SEG;
-    const uint32_t threads = nslots * rx.nwin * (rx.nent / seg_len);
+    const uint32_t threads = nslots * (rx.slot_ent / seg_len);
     if (!g2) k_g16_build_table<fq, 20><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table, msm_form ? 1u : 0u, rx);
     else k_g16_build_table<fq2, 40><<<(threads + TW - 1) / TW, TW, 0, st>>>(bases, nslots, table, msm_form ? 1u : 0u, rx);
 }

@@ -23,16 +23,41 @@ namespace zkp {
 #ifndef ZKP_G16_WBITS
 #define ZKP_G16_WBITS 14
 #endif
-struct G16Radix { uint32_t wbits, nwin, nent, digw, nwin_u64; };
-ZKP_HD inline G16Radix g16_radix(uint32_t wbits) {
-    G16Radix r; r.wbits = wbits; r.nwin = (254 + wbits) / wbits; r.nent = 1u << (wbits - 1); r.digw = (r.nwin + 1) / 2; r.nwin_u64 = (64 + wbits) / wbits;
-    return r;                           // nwin * wbits >= 255 and nwin_u64 * wbits >= 65: the windows cover the scalar and the recoding carry
+// Radix of a key's window tables.  Even form: nwin windows of wbits bits, nent = 2^(wbits-1) entries each (signed digits).  Uneven form
+// (wbits = 14 only): a 254-bit scalar in 18 windows instead of 19 -- at 19 x 14 bits the last window holds two bits and four of its 8192
+// entries are ever read -- as sixteen 14-bit windows, one 15-bit window (signed digits, 2 nent entries) and the top 15 bits (bits 239..253 of
+// a scalar < r: unsigned digits <= 24 784, no carry leaves it): one addition fewer per full-width scalar for 172 544 instead of 155 648
+// entries per base.  Scalars of the short classes (64-bit values, bits) only touch the 14-bit windows.
+struct G16Radix { uint32_t wbits, nwin, nent, digw, nwin_u64, uneven, slot_ent; };
+constexpr uint32_t G16_UNEVEN_TOP_ENT = 25088;          // 49 segments of 512 >= 24 784
+ZKP_HD inline G16Radix g16_radix(uint32_t wbits, bool uneven = false) {
+    G16Radix r; r.wbits = wbits; r.nwin = (254 + wbits) / wbits; r.nent = 1u << (wbits - 1); r.nwin_u64 = (64 + wbits) / wbits; r.uneven = 0;
+    r.slot_ent = r.nwin * r.nent;       // nwin * wbits >= 255 and nwin_u64 * wbits >= 65: the windows cover the scalar and the recoding carry
+    if (uneven && wbits == 14) { r.uneven = 1; r.nwin = 18; r.slot_ent = 18u * r.nent + G16_UNEVEN_TOP_ENT; }
+    r.digw = (r.nwin + 1) / 2;
+    return r;
 }
+ZKP_HD inline uint32_t g16_win_bit(const G16Radix& rx, uint32_t w) { return rx.uneven && w == 17 ? 239u : rx.wbits * w; }      // first bit of window w
+ZKP_HD inline uint32_t g16_win_off(const G16Radix& rx, uint32_t w) { return (w + (rx.uneven && w == 17 ? 1u : 0u)) * rx.nent; }  // first entry of window w in a base's block
+ZKP_HD inline uint32_t g16_win_ent(const G16Radix& rx, uint32_t w) { return !rx.uneven || w < 16 ? rx.nent : w == 16 ? 2u * rx.nent : G16_UNEVEN_TOP_ENT; }
 constexpr uint32_t G16_WBITS_DEFAULT = ZKP_G16_WBITS, G16_WBITS_MIN = 8, G16_WBITS_MAX = 15, G16_DIGW_MAX = 16;      // radix 2^8: 32 windows = 16 digit words
 static_assert(G16_WBITS_DEFAULT >= G16_WBITS_MIN && G16_WBITS_DEFAULT <= G16_WBITS_MAX, "key-table radix out of range");
-// packed signed digits of a raw canonical scalar at radix 2^wbits (packed[] holds G16_DIGW_MAX words; the first rx.digw are meaningful)
-ZKP_HD inline void g16_recode(uint32_t* packed, const sc& raw, uint32_t wbits) {
-    switch (wbits) {
+// packed signed digits of a raw canonical scalar at the radix rx (packed[] holds G16_DIGW_MAX words; the first rx.digw are meaningful)
+ZKP_HD inline void g16_recode_uneven(uint32_t* packed, const sc& raw) {
+    uint32_t carry = 0;
+    ZKP_UNROLL for (int j = 0; j < 18; j++) {
+        const int bit = j == 17 ? 239 : 14 * j, wb = j < 16 ? 14 : 15, wd = bit >> 5, sh = bit & 31;
+        uint32_t x = wd < 8 ? raw.v[wd] >> sh : 0u;
+        if (sh + wb > 32 && wd + 1 < 8) x |= raw.v[wd + 1] << (32 - sh);
+        uint32_t d = (x & ((1u << wb) - 1u)) + carry;
+        carry = j < 17 && d > (1u << (wb - 1)) ? 1u : 0u;          // the top window keeps its digit unsigned: nothing above it takes a carry
+        d = (d - (carry << wb)) & 0xffffu;
+        if ((j & 1) == 0) packed[j >> 1] = d; else packed[j >> 1] |= d << 16;
+    }
+}
+ZKP_HD inline void g16_recode(uint32_t* packed, const sc& raw, const G16Radix& rx) {
+    if (rx.uneven) { g16_recode_uneven(packed, raw); return; }
+    switch (rx.wbits) {
         case 8: sc_recode_signed<8, 32>(packed, raw); break;
         case 9: sc_recode_signed<9, 29>(packed, raw); break;
         case 10: sc_recode_signed<10, 26>(packed, raw); break;
@@ -66,7 +91,7 @@ ZKP_HD inline void g16_put_bytes(uint8_t* dst, const uint32_t* w, int nwords) {
 // packed signed digits of a Montgomery-form Fr element (canonical value < r < 2^254)
 ZKP_HD inline void st_fr_digits(uint32_t* d, uint32_t idx, uint32_t row, uint32_t rows, const fr& x, const G16Radix& rx) {
     sc raw; fp_to_raw(raw.v, x);
-    uint32_t pk[G16_DIGW_MAX]; g16_recode(pk, raw, rx.wbits);
+    uint32_t pk[G16_DIGW_MAX]; g16_recode(pk, raw, rx);
     uint32_t* q = d + (size_t)idx * rx.digw * rows + row;
     ZKP_UNROLL for (uint32_t k = 0; k < G16_DIGW_MAX; k++) if (k < rx.digw) q[(size_t)k * rows] = pk[k];
 }

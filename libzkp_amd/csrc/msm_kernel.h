@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
     };
     auto fetch = [&](uint4* e, uint32_t slot, uint32_t win, int32_t d) {
         if (d == 0) return;
-        const uint4* src = table4 + (((size_t)m.slot_base[slot] * m.nwin + win) * m.nent + (uint32_t)((d < 0 ? -d : d) - 1)) * V4;
+        const uint4* src = table4 + ((size_t)m.slot_base[slot] * m.slot_ent + (size_t)(win + (m.uneven && win == 17u ? 1u : 0u)) * m.nent + (uint32_t)((d < 0 ? -d : d) - 1)) * V4;
         ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) e[k] = src[k];
     };
     if (left == 0) { if (active) T::store(m.partial, chunk, row, m.rows, T::from_gather(acc)); return; }
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
         uint4* const wbuf = gather_lds + (size_t)wave * (2u * V4 * 64u);
         auto dma = [&](uint32_t buf, uint32_t slot, uint32_t win, int32_t dd) {
             if (dd == 0) return;
-            const uint4* src = table4 + (((size_t)m.slot_base[slot] * m.nwin + win) * m.nent + (uint32_t)((dd < 0 ? -dd : dd) - 1)) * V4;
+            const uint4* src = table4 + ((size_t)m.slot_base[slot] * m.slot_ent + (size_t)(win + (m.uneven && win == 17u ? 1u : 0u)) * m.nent + (uint32_t)((dd < 0 ? -dd : dd) - 1)) * V4;
             ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) __builtin_amdgcn_global_load_lds(src + k, wbuf + (buf * V4 + k) * 64u, 16, 0, 0);
         };
         uint32_t cb = 0;

@@ -18,7 +18,7 @@ int emul_g16_witness_qap(int kind, uint64_t value, const uint64_t* set_vals, uin
     ensure_mimc_constants();
     std::vector<uint32_t> mc; for (auto& c : g_mimc_host) put_fr(mc, c);
     const uint32_t nsc = g16_nscalars(T.nv, T.m);
-    const G16Radix rx = g16_radix(radix_bits ? radix_bits : G16_WBITS_DEFAULT);
+    const G16Radix rx = radix_bits == 114 ? g16_radix(14, true) : g16_radix(radix_bits ? radix_bits : G16_WBITS_DEFAULT);          // 114: the uneven form of radix 2^14
     std::vector<uint32_t> z((size_t)T.nv * 8), sdig((size_t)nsc * rx.digw), rs(16), seedw(8);
     memcpy(seedw.data(), seed, 32);
     uint64_t sv[G16_MAX_SET] = {0}; for (uint32_t i = 0; i < set_len && i < G16_MAX_SET; i++) sv[i] = set_vals[i];
@@ -39,10 +39,11 @@ int emul_g16_witness_qap(int kind, uint64_t value, const uint64_t* set_vals, uin
     // digits -> canonical value (sum d_j 2^(WBITS j)), as 8 words
     auto undigit = [&](uint32_t idx, uint32_t* outw) {
         unsigned __int128 lo = 0, hi = 0;     // 260-bit accumulator as two halves: value = hi * 2^128 + lo (two's complement overall)
-        // Horner from the top digit: acc = acc * 2^WBITS + d
+        // Horner from the top digit: acc = acc * 2^(distance to the next window) + d
         for (int j = (int)rx.nwin - 1; j >= 0; j--) {
             const int32_t d = (int32_t)(int16_t)(sdig[(size_t)idx * rx.digw + (j >> 1)] >> (16 * (j & 1)));
-            hi = (hi << rx.wbits) | (lo >> (128 - rx.wbits)); lo <<= rx.wbits;
+            const uint32_t sh = j + 1 < (int)rx.nwin ? g16_win_bit(rx, (uint32_t)j + 1) - g16_win_bit(rx, (uint32_t)j) : rx.wbits;
+            hi = (hi << sh) | (lo >> (128 - sh)); lo <<= sh;
             if (d >= 0) { const unsigned __int128 t = lo + (unsigned)d; if (t < lo) hi++; lo = t; }
             else { const unsigned __int128 t = lo - (unsigned)(-d); if (t > lo) hi--; lo = t; }
         }

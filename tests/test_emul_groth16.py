@@ -220,7 +220,7 @@ def test_digit_rows_at_every_key_table_radix(libs):
     _, lib = libs
     seed = bytes(range(32))
     want = _run(lib, 0, 42, [], seed)
-    for wb in (8, 9, 10, 11, 12, 13, 15):
+    for wb in (8, 9, 10, 11, 12, 13, 14, 15, 114):          # 114: radix 2^14 in its uneven form (18 windows), the default when it fits
         got = _run(lib, 0, 42, [], seed, wb)
         assert got == want, wb
 

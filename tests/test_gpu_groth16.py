@@ -235,10 +235,15 @@ def test_key_tables_are_sized_at_load_time_and_the_bytes_do_not_change():
             assert load() == [0, 0], _native.last_error()
             assert _prove_some(L) == want, wb
         del os.environ["ZKP_HIP_G16_WBITS"]
+        os.environ.pop("ZKP_HIP_G16_TABLE_BUDGET_MB", None)
+        os.environ["ZKP_HIP_G16_UNEVEN"] = "0"                     # radix 2^14 in its even form (19 windows) against the default's uneven form (18)
+        assert load() == [0, 0], _native.last_error()
+        assert _prove_some(L) == want, "even 2^14"
+        del os.environ["ZKP_HIP_G16_UNEVEN"]
         os.environ["ZKP_HIP_G16_TABLE_BUDGET_MB"] = "100"
         assert load()[0] < 0 and "not enough device memory" in _native.last_error()
     finally:
-        os.environ.pop("ZKP_HIP_G16_TABLE_BUDGET_MB", None); os.environ.pop("ZKP_HIP_G16_WBITS", None)
+        os.environ.pop("ZKP_HIP_G16_TABLE_BUDGET_MB", None); os.environ.pop("ZKP_HIP_G16_WBITS", None); os.environ.pop("ZKP_HIP_G16_UNEVEN", None)
         assert load() == [0, 0], _native.last_error()
     assert _prove_some(L) == want
 
