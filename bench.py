@@ -23,6 +23,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with
   roofline       the dominant kernel of the mixed batch, k_msm_gather<G1Msm> (Groth16 key-point MSMs), against the HBM roof
   roofline_valu  the same kernel against the VALU integer roof that actually binds it
   cpu_baseline   oracle/c's process_batch port (OpenMP over ops, like rayon) on a bounded sample of the same ops.
+and at N = 1, beside the contract's keys: host_buffers, two_batches_in_flight, other_configs_staged (C2 / C3 / C4 on their own) and
+verification_c_abi (4096 Groth16 equality envelopes and 4096 range envelopes through the C ABI).
 The timed region runs with the library's per-launch event profiling OFF; the launch durations behind `roofline` come from a second
 pass of the same K steps with it on (`profiled_pass` holds that pass's step time: the cost of the instrumentation is visible).
 """
