@@ -23,8 +23,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with
   roofline       the dominant kernel of the mixed batch, k_msm_gather<G1Msm> (Groth16 key-point MSMs), against the HBM roof
   roofline_valu  the same kernel against the VALU integer roof that actually binds it
   cpu_baseline   oracle/c's process_batch port (OpenMP over ops, like rayon) on a bounded sample of the same ops.
-and at N = 1, beside the contract's keys: host_buffers, two_batches_in_flight, other_configs_staged (C2 / C3 / C4 on their own) and
-verification_c_abi (4096 Groth16 equality envelopes and 4096 range envelopes through the C ABI).
+and at N = 1, beside the contract's keys: host_buffers, two_batches_in_flight, other_configs_staged (C2 / C3 / C4 on their own),
+batch_size_sweep (the mixed batch at 512 ... 16 384 ops) with predicted_strong_scaling (what one 16 384-op batch over N GPUs can reach, from
+this one GPU's step times), g16_table_radix / g16_table_bytes (which key tables produced `value`) and verification_c_abi (4096 Groth16 equality envelopes and 4096 range envelopes through the C ABI).
 The timed region runs with the library's per-launch event profiling OFF; the launch durations behind `roofline` come from a second
 pass of the same K steps with it on (`profiled_pass` holds that pass's step time: the cost of the instrumentation is visible).
 """
@@ -50,8 +51,28 @@ MADS_PER_G1_MADD = 7 * 162 + 2 * 126 + 243      # g1_mmadd9 (XYZZ, nine 29-bit l
 G1_BARE_LOOP_GADDS = 16.99               # G additions/s of the bare addition loop at 3 waves/SIMD, no loads (tools/g1_add_rate.hip, profiles/r02_g1_add_rate.jsonl)
 MADS_PER_ED_MADD = 7 * 100               # mixed addition with an affine-Niels entry: 7 GF(2^255-19) products of 100 mads
 ALGO_BYTES = {"range": 24 + 32 + 1478, "equality": 16 + 32 + 298, "membership16": 8 + 128 + 32 + 430}
-ALONE_CSV = os.path.join(ROOT, "profiles", "r03_kernel_alone.csv")      # per-kernel durations with every dispatch serialised (counter pass)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
+def _latest(name):
+    """profiles/rNN_<name> of the latest round that has one"""
+    for r in range(9, 0, -1):
+        path = os.path.join(ROOT, "profiles", "r%02d_%s" % (r, name))
+        if os.path.exists(path):
+            return path
+    return os.path.join(ROOT, "profiles", "r04_" + name)
+
+
+ALONE_CSV = _latest("kernel_alone.csv")      # per-kernel durations with every dispatch serialised (counter pass)
+TRAFFIC_JSON = _latest("traffic.json")
+XGMI_LINK_GBS = 153.0                    # per link and direction (MI355X_MICROARCH.md); a ring all_gather is bound by one link
+
+
+def csrc_sha16():
+    """Identifies the kernel sources a profile was taken on: sha256 over libzkp_amd/csrc (names + contents), first 16 hex digits."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "libzkp_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _free_port():
@@ -109,6 +130,12 @@ def alone_durations():
         return {}
     with open(ALONE_CSV) as f:
         return {r["kernel"]: {"avg_ms": float(r["avg_ms"]), "launches_per_step": float(r["launches_per_step"])} for r in csv.DictReader(f)}
+
+
+def alone_build():
+    """The build the serialised pass was taken on (sidecar written by tools/kernel_alone.py), so that a stale file is visible in the line."""
+    meta = ALONE_CSV.replace(".csv", ".meta.json")
+    return json.load(open(meta)).get("csrc_sha16") if os.path.exists(meta) else None
 
 
 def in_library_child(devices, nt, steps):
@@ -204,6 +231,12 @@ def main():
         blob = open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
         keys.append((kind, blob))
         _native.check(L.zkp_hip_groth16_load_key(kind, blob, len(blob)), "zkp_hip_groth16_load_key")
+
+    key_info = {}
+    for kind, nm in ((0, "equality"), (1, "membership")):
+        wb, un, tb = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+        _native.check(L.zkp_hip_groth16_key_info(kind, ctypes.byref(wb), ctypes.byref(un), ctypes.byref(tb)), "zkp_hip_groth16_key_info")
+        key_info[nm] = {"radix": "2^%d%s" % (wb.value, " uneven (18 windows)" if un.value else ""), "table_bytes": tb.value}
 
     def barrier():
         torch.cuda.synchronize()
@@ -345,6 +378,37 @@ def main():
             extra["other_configs_staged"] = other
         except Exception as e:  # noqa: BLE001
             extra["extra_legs_error"] = repr(e)[:400]
+        try:
+            # One 16 384-op batch over N GPUs gives every GPU 16 384 / N ops of the same mix (batch.rs:123-131 fanned out; zkp_hip_plan_shards):
+            # the step time of the mixed batch against its size on THIS GPU says what N GPUs can reach -- a batch has a fixed cost (the ~50
+            # dependent launches of the Bulletproofs chain, the Groth16 latency kernels) that does not shrink with its share.
+            sweep = {}
+            for nb in (512, 1024, 2048, 4096, 8192, 16384):
+                o_s, l_s, s_s = wl.mixed_ops(nb, 5)
+                h_s = ctypes.c_void_p()
+                _native.check(L.zkp_hip_batch_stage(nb, P(o_s), P(l_s), P(s_s), ctypes.byref(h_s)), "stage (sweep)")
+                t_s = timed(lambda: _native.check(L.zkp_hip_batch_prove(h_s), "prove (sweep)"), 7 if nb <= 4096 else 4)
+                cap_s = int(L.zkp_hip_batch_max_bytes(h_s))
+                # the local half of the hand-over a sharded step pays: packed proofs of the staged batch -> the caller's device buffer
+                buf_s = torch.zeros(cap_s, dtype=torch.uint8, device=dev)
+                t_d = timed(lambda: _native.check(L.zkp_hip_batch_device_results(h_s, 0, buf_s.data_ptr(), cap_s, None, None, None), "device_results (sweep)"), 5)
+                L.zkp_hip_batch_free(h_s)
+                sweep[str(nb)] = {"ms_per_batch": t_s * 1e3, "proofs_per_s": nb / t_s, "packed_bytes_capacity": cap_s, "device_results_ms": t_d * 1e3}
+            extra["batch_size_sweep"] = sweep
+            t16 = sweep["16384"]["ms_per_batch"]
+            pred = {}
+            for N in (2, 4, 8):
+                sh = sweep[str(16384 // N)]
+                # blocking all_gather of every rank's packed proofs: each rank receives (N - 1) / N of the total through a ring bound by one
+                # xGMI link; MODELLED (one GPU here), at 70 % of the link rate plus 20 us per ring step
+                gather_ms = sweep["16384"]["packed_bytes_capacity"] * (N - 1) / N / (0.7 * XGMI_LINK_GBS * 1e9) * 1e3 + 0.02 * (N - 1)
+                pred[str(N)] = {"share_ms": sh["ms_per_batch"], "device_results_ms": sh["device_results_ms"], "gather_ms_modelled": gather_ms,
+                                "speedup": t16 / (sh["ms_per_batch"] + sh["device_results_ms"] + gather_ms)}
+            extra["predicted_strong_scaling"] = {"t_16384_ms": t16, "by_n_gpus": pred,
+                                                 "note": "t(16 384 ops on one GPU) / (t(16 384 / N ops on one GPU) + measured local hand-over + modelled ring all_gather); "
+                                                         "a prediction from ONE GPU -- no multi-GPU run was made by this command"}
+        except Exception as e:  # noqa: BLE001
+            extra["sweep_leg_error"] = repr(e)[:400]
         try:                                                         # SURVEY 8f row N2 beside the contract's line: batched verification through the C ABI
             nv = 4096
             rngv = np.random.default_rng(5)
@@ -445,7 +509,8 @@ def main():
             alone_valu = {"avg_launch_ms": a_g1["avg_ms"], "achieved": rate, "frac": rate / MAD_ISSUE_T,
                           "g_additions_per_s": adds_per_launch / (a_g1["avg_ms"] * 1e-3) / 1e9,
                           "fraction_of_bare_loop": adds_per_launch / (a_g1["avg_ms"] * 1e-3) / 1e9 / G1_BARE_LOOP_GADDS,
-                          "hbm_frac": algo_launch / (a_g1["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "source": "profiles/r03_kernel_alone.csv"}
+                          "hbm_frac": algo_launch / (a_g1["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "source": os.path.relpath(ALONE_CSV, ROOT),
+                          "profiled_build": alone_build(), "this_build": csrc_sha16(), "stale": alone_build() != csrc_sha16()}
         floor = sum(v["avg_ms"] * v["launches_per_step"] for k, v in alone.items() if k in ("k_msm_gather<G1Msm>", "k_msm_gather<G2Msm>", "k_msm_dma<EdMsm>", "k_g16_qap", "k_stark_prove"))
         res = {
             "metric": "proofs/sec (whole node) + ms/proof p50, 4096-proof mixed batch (range / equality / membership / improvement) per MI355X",
@@ -463,6 +528,12 @@ def main():
             "profiled_pass": {"ms_per_step": dt_prof / args.steps * 1e3, "note": "the same K steps again with an event pair around every MSM launch (zkp_hip_profile_enable): "
                                                                               "the source of the launch durations below; its step time shows what the instrumentation costs"},
             "kernel_floor_ms_per_step": floor if floor else None,
+            "kernel_floor_source": {"file": os.path.relpath(ALONE_CSV, ROOT), "profiled_build": alone_build(), "this_build": csrc_sha16(), "stale": alone_build() != csrc_sha16(),
+                                    "note": "sum of the GPU-filling kernels' durations from a serialised rocprofv3 counter pass of this command (tools/profile_round.sh), "
+                                            "not measured by this run: `stale` says whether the kernel sources have changed since"},
+            "g16_table_radix": {k: v["radix"] for k, v in key_info.items()}, "g16_table_bytes": sum(v["table_bytes"] for v in key_info.values()),
+            "g16_table_policy": "library default (radix 2^13; ZKP_HIP_G16_TABLE_BUDGET_MB opts into larger tables)" if not (os.environ.get("ZKP_HIP_G16_TABLE_BUDGET_MB") or os.environ.get("ZKP_HIP_G16_WBITS"))
+                                else "environment: ZKP_HIP_G16_TABLE_BUDGET_MB=%s ZKP_HIP_G16_WBITS=%s" % (os.environ.get("ZKP_HIP_G16_TABLE_BUDGET_MB"), os.environ.get("ZKP_HIP_G16_WBITS")),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_msm_gather<G1Msm>",
                          "avg_launch_ms": g1_avg_ms, "launches": g1[1], "algorithmic_bytes_per_launch": algo_launch,

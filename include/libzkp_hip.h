@@ -101,6 +101,12 @@ int zkp_hip_prove_consistency_batch(uint64_t n, const uint64_t* data, const uint
  * pk = ark-serialize *uncompressed* ProvingKey<Bn254> bytes, i.e. the content of the reference's
  * `{prefix}_pk.bin` key files (snark.rs:31-38,97-112).  Builds the fixed-base tables of every key point on the GPU. */
 int zkp_hip_groth16_load_key(int kind, const uint8_t* pk, uint64_t len);
+/* What the loaded key of `kind` holds on the calling thread's shard: the radix of its fixed-base window tables (2^*wbits; *uneven = 1:
+ * the 18-window form of radix 2^14) and the HBM they occupy (shared by the shards of one GPU).  Default policy: radix 2^13, ~34 GB for
+ * the two circuits together; ZKP_HIP_G16_TABLE_BUDGET_MB=<MB per key> opts into larger tables (2^14-uneven, ~72 GB, measured 1.7 %
+ * faster on the mixed batch), ZKP_HIP_G16_WBITS=8..15 forces a radix; a device with less free memory gets a smaller radix.  The
+ * reference keeps a ProvingKey in host memory (snark.rs:40-56); this is the device-side cost of its replacement.  Any pointer may be NULL. */
+int zkp_hip_groth16_key_info(int kind, uint32_t* wbits, uint32_t* uneven, uint64_t* table_bytes);
 
 /* Circuit-specific trusted setup (replaces Groth16::circuit_specific_setup at snark.rs:318,337): toxic waste from
  * `setup_seed` (32 bytes; NULL = OS randomness, the reference's behaviour), every key point computed on the GPU.

@@ -14,7 +14,7 @@ RANGE_PROOF_BYTES = 1478
 EXPORTS = (
     "zkp_hip_init", "zkp_hip_shutdown", "zkp_hip_last_error", "zkp_hip_prove_range_batch",
     "zkp_hip_prove_range_batch_device", "zkp_hip_prove_threshold_batch", "zkp_hip_prove_consistency_batch",
-    "zkp_hip_consistency_proof_bytes", "zkp_hip_range_proof_bytes", "zkp_hip_threshold_proof_bytes", "zkp_hip_groth16_load_key", "zkp_hip_groth16_generate_key", "zkp_hip_snark_commit_value_batch",
+    "zkp_hip_consistency_proof_bytes", "zkp_hip_range_proof_bytes", "zkp_hip_threshold_proof_bytes", "zkp_hip_groth16_load_key", "zkp_hip_groth16_key_info", "zkp_hip_groth16_generate_key", "zkp_hip_snark_commit_value_batch",
     "zkp_hip_prove_equality_batch", "zkp_hip_prove_membership_batch", "zkp_hip_improvement_max_bytes", "zkp_hip_prove_improvement_batch",
     "zkp_hip_prove_improvement_batch_device", "zkp_hip_verify_range_batch", "zkp_hip_verify_threshold_batch", "zkp_hip_verify_consistency_batch", "zkp_hip_verify_equality_batch", "zkp_hip_verify_membership_batch",
     "zkp_hip_verify_improvement_batch", "zkp_hip_process_batch", "zkp_hip_profile_enable", "zkp_hip_profile_read", "zkp_hip_set_window_budget", "zkp_hip_set_subbatches", "zkp_hip_set_msm_variant",
@@ -80,6 +80,8 @@ def lib():
             f.restype = u64
         L.zkp_hip_groth16_load_key.argtypes = [ctypes.c_int, vp, u64]
         L.zkp_hip_groth16_load_key.restype = ctypes.c_int
+        L.zkp_hip_groth16_key_info.argtypes = [ctypes.c_int, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u64)]
+        L.zkp_hip_groth16_key_info.restype = ctypes.c_int
         L.zkp_hip_groth16_generate_key.argtypes = [ctypes.c_int, vp, vp, u64, ctypes.POINTER(u64), vp, u64, ctypes.POINTER(u64)]
         L.zkp_hip_groth16_generate_key.restype = ctypes.c_int
         L.zkp_hip_snark_commit_value_batch.argtypes = [u64, vp, vp]

@@ -71,7 +71,9 @@ int g16_vm_upload(G16VmTables& T) {          // (g16_vm_free is declared in g16_
     rc |= up(fq2vm::SCRIPT_SUBGROUP, sizeof(fq2vm::SCRIPT_SUBGROUP), (const void**)&T.script[1]);
     rc |= up(fq2vm::SCRIPT_FINISH, sizeof(fq2vm::SCRIPT_FINISH), (const void**)&T.script[2]);
     rc |= up(fq2vm::SCRIPT_MILLER_B, sizeof(fq2vm::SCRIPT_MILLER_B), (const void**)&T.script[3]);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_fq2vm), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_fq2vm), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        (void)hipGetLastError(); g16_vm_free(T); return -2;          // the 160 KB LDS opt-in of the Fq2 machine was refused: say so here, not as an opaque launch error later
+    }
     for (auto& q : T.side) if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) rc = -1;
     for (auto& e : T.ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = -1;
     if (rc) { g16_vm_free(T); return -1; }          // a partial upload leaves nothing behind

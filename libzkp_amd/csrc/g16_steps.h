@@ -40,7 +40,7 @@ ZKP_HD inline G16Radix g16_radix(uint32_t wbits, bool uneven = false) {
 ZKP_HD inline uint32_t g16_win_bit(const G16Radix& rx, uint32_t w) { return rx.uneven && w == 17 ? 239u : rx.wbits * w; }      // first bit of window w
 ZKP_HD inline uint32_t g16_win_off(const G16Radix& rx, uint32_t w) { return (w + (rx.uneven && w == 17 ? 1u : 0u)) * rx.nent; }  // first entry of window w in a base's block
 ZKP_HD inline uint32_t g16_win_ent(const G16Radix& rx, uint32_t w) { return !rx.uneven || w < 16 ? rx.nent : w == 16 ? 2u * rx.nent : G16_UNEVEN_TOP_ENT; }
-constexpr uint32_t G16_WBITS_DEFAULT = ZKP_G16_WBITS, G16_WBITS_MIN = 8, G16_WBITS_MAX = 15, G16_DIGW_MAX = 16;      // radix 2^8: 32 windows = 16 digit words
+constexpr uint32_t G16_WBITS_DEFAULT = ZKP_G16_WBITS, G16_WBITS_KNEE = 13, G16_WBITS_MIN = 8, G16_WBITS_MAX = 15, G16_DIGW_MAX = 16;      // radix 2^8: 32 windows = 16 digit words
 static_assert(G16_WBITS_DEFAULT >= G16_WBITS_MIN && G16_WBITS_DEFAULT <= G16_WBITS_MAX, "key-table radix out of range");
 // packed signed digits of a raw canonical scalar at the radix rx (packed[] holds G16_DIGW_MAX words; the first rx.digw are meaningful)
 ZKP_HD inline void g16_recode_uneven(uint32_t* packed, const sc& raw) {

@@ -14,6 +14,9 @@
 #include <thread>
 #include <condition_variable>
 #include <functional>
+#include <deque>
+#include <new>
+#include <exception>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -163,6 +166,44 @@ namespace {
 
 thread_local std::string t_err;
 int fail(int code, const std::string& msg) { t_err = msg; return code; }
+// ---- Exception barrier of the C ABI ("per-item status code + message; never abort" -- batch.rs:126-130 turns every failure
+// into an Err, error_handling.rs:39-50 maps it for Python).  Every exported function is a function-try-block that ends in one of these
+// handlers: a std::bad_alloc / std::system_error / anything else raised by the host logic (vectors sized from the caller's n, strings,
+// worker threads, mutexes) becomes ZKP_HIP_E_RUNTIME with a message for zkp_hip_last_error instead of unwinding through a C frame into
+// the caller's Rust (undefined behaviour).  RAII releases what the call held (Bind, DevScope, vectors); the library stays usable.
+int fail_nothrow(int code, const char* what, const char* detail) noexcept {
+    try { t_err.assign(what); if (detail) t_err.append(detail); }
+    catch (...) { t_err.clear(); try { t_err.assign("out of memory"); } catch (...) {} }      // (fits the small-string buffer)
+    return code;
+}
+#define ZKP_API_CATCH_RET(on_fail)                                                                                                  \
+    catch (const std::bad_alloc&) { (void)fail_nothrow(ZKP_HIP_E_RUNTIME, "out of host memory", nullptr); on_fail; }                   \
+    catch (const std::exception& e_) { (void)fail_nothrow(ZKP_HIP_E_RUNTIME, "C++ exception at the C ABI: ", e_.what()); on_fail; }    \
+    catch (...) { (void)fail_nothrow(ZKP_HIP_E_RUNTIME, "unknown C++ exception at the C ABI", nullptr); on_fail; }
+#define ZKP_API_CATCH_INT ZKP_API_CATCH_RET(return ZKP_HIP_E_RUNTIME)
+#define ZKP_API_CATCH_ZERO ZKP_API_CATCH_RET(return 0)
+#define ZKP_API_CATCH_VOID ZKP_API_CATCH_RET(return)
+// the same for the body of a host worker thread (an exception that leaves a std::thread's function is std::terminate)
+template <class F> int guarded(F&& f) noexcept {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return fail_nothrow(ZKP_HIP_E_RUNTIME, "out of host memory", nullptr); }
+    catch (const std::exception& e_) { return fail_nothrow(ZKP_HIP_E_RUNTIME, "C++ exception in a shard worker: ", e_.what()); }
+    catch (...) { return fail_nothrow(ZKP_HIP_E_RUNTIME, "unknown C++ exception in a shard worker", nullptr); }
+}
+// Largest batch one call accepts: beyond it the workspaces (~110 KB of HBM per range op) cannot exist on a 288 GB device anyway, and
+// host vectors / pinned staging are sized from n -- an absurd n is an argument error, not an allocation attempt.
+constexpr uint64_t ZKP_MAX_BATCH_OPS = 1ull << 22;
+constexpr uint64_t ZKP_MAX_LIST_VALUES = 1ull << 28;      // threshold / consistency value lists of one call, summed
+int check_batch_size(uint64_t n) {
+    if (n > ZKP_MAX_BATCH_OPS) return fail(ZKP_HIP_E_ARGUMENT, "batch too large: at most 4194304 operations per call (split the batch)");
+    return 0;
+}
+// counts[] of a threshold / consistency call: the lists are read by index sums, so their total is bounded BEFORE anything is read or sized from it
+int check_list_total(uint64_t n, const uint32_t* counts) {
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; i++) { total += counts[i]; if (total > ZKP_MAX_LIST_VALUES) return fail(ZKP_HIP_E_ARGUMENT, "value lists too long: at most 2^28 values per call (split the batch)"); }
+    return 0;
+}
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
         hipError_t e_ = (expr);                                                                                \
@@ -291,22 +332,33 @@ struct Device {
 // that shard's worker instead of creating and joining a std::thread per shard per fan-out.  The thread touches HIP only inside a job; it is
 // never joined (nothing of this library is destroyed from exit(), see the registry below) and survives zkp_hip_shutdown parked.
 struct ShardWorker {
+    // A FIFO of jobs, each with its own completion flag: callers on different host threads (one staging batch N + 1 while another waits
+    // for batch N) may post to the same shard's worker at once; every caller waits for ITS tickets only, so no job is overwritten and
+    // nobody returns on somebody else's completion (round 3 kept ONE job slot behind a lock that every call site had its own copy of).
+    struct Job { std::function<void()> fn; bool done = false; };
+    using Ticket = std::shared_ptr<Job>;
     std::mutex mu; std::condition_variable cv;
-    std::function<void()> job; bool has_job = false, done = true;
+    std::deque<Ticket> queue;
     std::thread th;
     ShardWorker() : th([this]() { run(); }) { th.detach(); }
     void run() {
         for (;;) {
-            std::function<void()> f;
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this]() { return has_job; }); f = std::move(job); has_job = false; }
-            f();
-            { std::lock_guard<std::mutex> lk(mu); done = true; }
+            Ticket t;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this]() { return !queue.empty(); }); t = queue.front(); queue.pop_front(); }
+            t->fn();                                   // (posted bodies never throw: for_each_shard wraps them in guarded())
+            { std::lock_guard<std::mutex> lk(mu); t->done = true; }
             cv.notify_all();
         }
     }
-    void post(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu); job = std::move(f); has_job = true; done = false; } cv.notify_all(); }
-    void wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this]() { return done; }); }
+    Ticket post(std::function<void()> f) {
+        Ticket t = std::make_shared<Job>(); t->fn = std::move(f);
+        { std::lock_guard<std::mutex> lk(mu); queue.push_back(t); }
+        cv.notify_all();
+        return t;
+    }
+    void wait(const Ticket& t) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return t->done; }); }
 };
+std::mutex g_worker_create_mu;          // one lock for every call site (workers are created once per shard)
 // event pair around one profiled launch (nullptrs when profiling is off)
 int prof_begin(Device::KProf& K, hipStream_t st, hipEvent_t* e1);
 void prof_end(Device::KProf& K, hipStream_t st, hipEvent_t e1, uint64_t adds);
@@ -511,7 +563,7 @@ std::shared_ptr<std::vector<uint32_t>> host_generator_tables() {
     auto tab = std::make_shared<std::vector<uint32_t>>(words);
     ge gens[NBASE]; host_generators(gens);
     std::atomic<int> next{0};
-    auto work = [&]() { for (int b; (b = next.fetch_add(1)) < (int)NBASE;) host_build_table_for_base(tab->data() + (size_t)b * NWIN * SUBTAB_W, gens[b]); };
+    auto work = [&]() noexcept { for (int b; (b = next.fetch_add(1)) < (int)NBASE;) host_build_table_for_base(tab->data() + (size_t)b * NWIN * SUBTAB_W, gens[b]); };   // (no allocation inside)
     unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 16) nt = 16;
     std::vector<std::thread> pool;
     for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
@@ -573,18 +625,31 @@ int partition_cus(bool bp_part) { const int nb = bp_cus_per_xcd() * 8; return bp
 // second lane shared queues with the first one's, and two batches in flight measured slower than one: 15.1 against 13.6 ms per batch).
 int ensure_sub(SubBatch& sb, bool masked = false, SubBatch* share = nullptr) {
     if (sb.stream) return 0;
+    // Built in locals and committed to `sb` only when every object exists: a failure half-way (these are created lazily, in the middle of
+    // a batch enqueue) must not leave a slot that looks ready but holds null events.
+    hipStream_t stream = nullptr, side = nullptr; bool borrowed = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    auto undo = [&]() {
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (!borrowed) { if (stream) (void)hipStreamDestroy(stream); if (side) (void)hipStreamDestroy(side); }
+    };
+    int rc = 0;
     if (share && share != &sb) {
-        int rc = ensure_sub(*share, masked); if (rc) return rc;
-        sb.stream = share->stream; sb.side = share->side; sb.borrowed = true;
-    } else if (masked) { int rc; if ((rc = make_masked_stream(&sb.stream, true)) || (rc = make_masked_stream(&sb.side, true))) return rc; }
-    else {
-        HIP_TRY(hipStreamCreateWithPriority(&sb.stream, hipStreamNonBlocking, stream_priority(bp_priority_level())));
-        HIP_TRY(hipStreamCreateWithPriority(&sb.side, hipStreamNonBlocking, stream_priority(bp_priority_level())));
+        if ((rc = ensure_sub(*share, masked))) return rc;
+        stream = share->stream; side = share->side; borrowed = true;
+    } else if (masked) {
+        if ((rc = make_masked_stream(&stream, true)) || (rc = make_masked_stream(&side, true))) { undo(); return rc; }
+    } else {
+        hipError_t e = hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, stream_priority(bp_priority_level()));
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, stream_priority(bp_priority_level()));
+        if (e != hipSuccess) { undo(); return fail(ZKP_HIP_E_RUNTIME, std::string("hipStreamCreateWithPriority: ") + hipGetErrorString(e)); }
     }
-    HIP_TRY(hipEventCreateWithFlags(&sb.start, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&sb.done, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&sb.side_go, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&sb.side_done, hipEventDisableTiming));
+    for (auto& e : ev) {
+        const hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (err != hipSuccess) { e = nullptr; undo(); return fail(ZKP_HIP_E_RUNTIME, std::string("hipEventCreateWithFlags: ") + hipGetErrorString(err)); }
+    }
+    sb.start = ev[0]; sb.done = ev[1]; sb.side_go = ev[2]; sb.side_done = ev[3];
+    sb.side = side; sb.borrowed = borrowed; sb.stream = stream;
     return 0;
 }
 
@@ -757,7 +822,7 @@ int prove_range_device_locked(uint64_t n, const uint64_t* d_value, const uint64_
                               const uint8_t* d_seeds, uint8_t* d_out, uint64_t stride, uint32_t* d_out_len, int32_t* d_status,
                               hipStream_t st, int* any_failed, int slot_hint = -1, bool masked = false) {
     if (n == 0) { if (any_failed) *any_failed = 0; return 0; }
-    if (n > (1u << 30)) return fail(ZKP_HIP_E_ARGUMENT, "batch too large");
+    { int rcn = check_batch_size(n); if (rcn) return rcn; }
     if (stride < range_envelope_bytes(lg)) return fail(ZKP_HIP_E_ARGUMENT, "stride is smaller than the proof (1478 bytes for n_bits = 64)");
     int rc;
     if ((rc = ensure_family(lg))) return rc;
@@ -941,11 +1006,11 @@ int frame_consistency(uint64_t n, const uint64_t* data, const uint32_t* counts, 
 extern "C" {
 
 const char* zkp_hip_last_error(void) { return t_err.c_str(); }
-void zkp_hip_set_window_budget(uint32_t budget) { g_budget_request = budget; }
-void zkp_hip_set_subbatches(uint32_t n) { g_subbatches = n; }
-void zkp_hip_set_msm_variant(uint32_t v) { if (v >= 100) g_fill = v / 100.0; }   // benchmarking knob: grid fill target x100 (single kernel variant remains)
+void zkp_hip_set_window_budget(uint32_t budget) try { g_budget_request = budget; } ZKP_API_CATCH_VOID
+void zkp_hip_set_subbatches(uint32_t n) try { g_subbatches = n; } ZKP_API_CATCH_VOID
+void zkp_hip_set_msm_variant(uint32_t v) try { if (v >= 100) g_fill = v / 100.0; } ZKP_API_CATCH_VOID   // benchmarking knob: grid fill target x100 (single kernel variant remains)
 
-int zkp_hip_init(int device) {
+int zkp_hip_init(int device) try {
     Device* d = nullptr;
     {
         Registry& R = registry();
@@ -961,9 +1026,9 @@ int zkp_hip_init(int device) {
     Bind bind; int rc = bind.open(d);
     drop_host_generator_tables();
     return rc;
-}
+} ZKP_API_CATCH_INT
 
-int zkp_hip_init_devices(uint32_t count, const int* devices) {
+int zkp_hip_init_devices(uint32_t count, const int* devices) try {
     if (count == 0 || count > 64 || !devices) return fail(ZKP_HIP_E_ARGUMENT, "zkp_hip_init_devices: 1..64 shards");
     std::vector<Device*> mine;
     {
@@ -986,26 +1051,26 @@ int zkp_hip_init_devices(uint32_t count, const int* devices) {
     (void)host_generator_tables();                     // once, before the per-shard workers need it
     std::vector<int> rcs(count, 0); std::vector<std::string> errs(count);
     std::vector<std::thread> th;
-    for (uint32_t k = 0; k < count; k++) th.emplace_back([&, k]() { Bind bind; rcs[k] = bind.open(mine[k]); if (rcs[k]) errs[k] = t_err; });
+    for (uint32_t k = 0; k < count; k++) th.emplace_back([&, k]() { rcs[k] = guarded([&]() { Bind bind; return bind.open(mine[k]); }); if (rcs[k]) { try { errs[k] = t_err; } catch (...) {} } });
     for (auto& t : th) t.join();
     drop_host_generator_tables();
     for (uint32_t k = 0; k < count; k++) if (rcs[k]) return fail(rcs[k], errs[k]);
     return 0;
-}
+} ZKP_API_CATCH_INT
 
-int zkp_hip_device_count(void) { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); return (int)R.shards.size(); }
+int zkp_hip_device_count(void) try { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); return (int)R.shards.size(); } ZKP_API_CATCH_INT
 
-int zkp_hip_use_device(int shard) {
+int zkp_hip_use_device(int shard) try {
     Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu);
     if (shard < 0 || (shard > 0 && shard >= (int)R.shards.size())) return fail(ZKP_HIP_E_ARGUMENT, "zkp_hip_use_device: no such shard");
     t_sel = shard;
     return 0;
-}
+} ZKP_API_CATCH_INT
 
 // Releases every device resource of every shard and forgets the shard registration.  Also the library's atexit hook: it
 // runs while the HIP runtime is still alive, so nothing of ours (streams, events, allocations, code objects in use) is
 // left for the runtime's own exit-time teardown to trip over.  The Device objects themselves are never freed.
-void zkp_hip_shutdown(void) {
+void zkp_hip_shutdown(void) try {
     std::vector<Device*> shards;
     { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); shards.swap(R.shards); R.host_table.reset(); }
     t_sel = 0;
@@ -1039,16 +1104,16 @@ void zkp_hip_shutdown(void) {
         d->ready = false; d->profiling = false; d->max_chunks = 0; d->next_slot = 0; d->generation++;
         t_dev = prev;
     }
-}
+} ZKP_API_CATCH_VOID
 
-void zkp_hip_profile_enable(int on) {
+void zkp_hip_profile_enable(int on) try {
     std::vector<Device*> shards;      // (the registry lock is not held while a shard's is taken: Bind::open takes them in the other order)
     { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); shards = R.shards; }
     for (Device* d : shards) { std::lock_guard<std::mutex> dl(d->mu); d->profiling = on != 0; }
-}
+} ZKP_API_CATCH_VOID
 
 // accumulated over all shards
-int zkp_hip_profile_read_kernel(int which, double* ms, uint64_t* launches, uint64_t* point_adds, int reset) {
+int zkp_hip_profile_read_kernel(int which, double* ms, uint64_t* launches, uint64_t* point_adds, int reset) try {
     if (which < 0 || which > 2) return fail(ZKP_HIP_E_ARGUMENT, "unknown kernel id");
     std::vector<Device*> shards;
     { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); shards = R.shards; }
@@ -1067,14 +1132,14 @@ int zkp_hip_profile_read_kernel(int which, double* ms, uint64_t* launches, uint6
     if (launches) *launches = tl;
     if (point_adds) *point_adds = ta;
     return 0;
-}
-int zkp_hip_profile_read(double* msm_ms, uint64_t* msm_launches, uint64_t* msm_point_adds, int reset) {
+} ZKP_API_CATCH_INT
+int zkp_hip_profile_read(double* msm_ms, uint64_t* msm_launches, uint64_t* msm_point_adds, int reset) try {
     return zkp_hip_profile_read_kernel(0, msm_ms, msm_launches, msm_point_adds, reset);
-}
+} ZKP_API_CATCH_INT
 
 int zkp_hip_prove_range_batch_device(uint64_t n, const uint64_t* d_value, const uint64_t* d_min, const uint64_t* d_max, uint32_t n_bits,
                                      const uint8_t* d_seeds, uint8_t* d_out, uint64_t stride, uint32_t* d_out_len, int32_t* d_status,
-                                     void* stream, int* any_failed) {
+                                     void* stream, int* any_failed) try {
     uint32_t lg;
     if (!bits_to_lg(n_bits, &lg)) return fail(ZKP_HIP_E_UNSUPPORTED, "n_bits must be 8, 16, 32 or 64");
     if (!d_seeds) return fail(ZKP_HIP_E_ARGUMENT, "device entry point needs seeds");
@@ -1084,14 +1149,15 @@ int zkp_hip_prove_range_batch_device(uint64_t n, const uint64_t* d_value, const 
     rc = prove_range_device_locked(n, d_value, d_min, d_max, lg, d_seeds, d_out, stride, d_out_len, d_status, st, any_failed);
     if (rc) return rc;
     return (any_failed && *any_failed) ? 1 : 0;
-}
+} ZKP_API_CATCH_INT
 
 int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t* min, const uint64_t* max, uint32_t n_bits,
-                              const uint8_t* seeds, uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
+                              const uint8_t* seeds, uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) try {
     uint32_t lg;
     if (!bits_to_lg(n_bits, &lg)) return fail(ZKP_HIP_E_UNSUPPORTED, "n_bits must be 8, 16, 32 or 64");
     if (n == 0) return 0;
     if (!value || !min || !max || !out || !out_len || !status) return fail(ZKP_HIP_E_ARGUMENT, "null pointer argument");
+    { int rcn = check_batch_size(n); if (rcn) return rcn; }
     if (stride < range_envelope_bytes(lg)) return fail(ZKP_HIP_E_ARGUMENT, "stride is smaller than the proof (1478 bytes for n_bits = 64)");
     std::vector<uint8_t> fresh;
     if (!seeds) { int rc0 = fresh_seeds(fresh, n); if (rc0) return rc0; seeds = fresh.data(); }   // bulletproofs.rs:82-87
@@ -1121,18 +1187,19 @@ int zkp_hip_prove_range_batch(uint64_t n, const uint64_t* value, const uint64_t*
     }
     if (rc) { (void)hipStreamSynchronize(st); return rc; }
     return any ? 1 : 0;
-}
+} ZKP_API_CATCH_INT
 
-uint64_t zkp_hip_range_proof_bytes(uint32_t n_bits) { uint32_t lg; return bits_to_lg(n_bits, &lg) ? range_envelope_bytes(lg) : 0; }
-uint64_t zkp_hip_threshold_proof_bytes(uint32_t n_bits) { uint32_t lg; return bits_to_lg(n_bits, &lg) ? threshold_envelope_bytes(lg) : 0; }
-uint64_t zkp_hip_consistency_proof_bytes(uint32_t count) { return consistency_envelope_bytes(count); }
+uint64_t zkp_hip_range_proof_bytes(uint32_t n_bits) try { uint32_t lg; return bits_to_lg(n_bits, &lg) ? range_envelope_bytes(lg) : 0; } ZKP_API_CATCH_ZERO
+uint64_t zkp_hip_threshold_proof_bytes(uint32_t n_bits) try { uint32_t lg; return bits_to_lg(n_bits, &lg) ? threshold_envelope_bytes(lg) : 0; } ZKP_API_CATCH_ZERO
+uint64_t zkp_hip_consistency_proof_bytes(uint32_t count) try { return consistency_envelope_bytes(count); } ZKP_API_CATCH_ZERO
 
 int zkp_hip_prove_threshold_batch(uint64_t n, const uint64_t* values, const uint32_t* counts, const uint64_t* thresholds, uint32_t n_bits,
-                                  const uint8_t* seeds, uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
+                                  const uint8_t* seeds, uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) try {
     uint32_t lg;
     if (!bits_to_lg(n_bits, &lg)) return fail(ZKP_HIP_E_UNSUPPORTED, "n_bits must be 8, 16, 32 or 64");
     if (n == 0) return 0;
     if (!values || !counts || !thresholds || !out || !out_len || !status) return fail(ZKP_HIP_E_ARGUMENT, "null pointer argument");
+    { int rcn = check_batch_size(n); if (rcn || (rcn = check_list_total(n, counts))) return rcn; }
     if (stride < threshold_envelope_bytes(lg)) return fail(ZKP_HIP_E_ARGUMENT, "stride is smaller than the proof (762 bytes for n_bits = 64)");
     std::vector<uint8_t> fresh;
     if (!seeds) { int rc = fresh_seeds(fresh, n); if (rc) return rc; seeds = fresh.data(); }
@@ -1143,12 +1210,13 @@ int zkp_hip_prove_threshold_batch(uint64_t n, const uint64_t* values, const uint
     if (rc) return rc;
     if ((rc = run_host_jobs(H, seeds, n, out, stride * n, lg))) return rc;
     return any;
-}
+} ZKP_API_CATCH_INT
 
 int zkp_hip_prove_consistency_batch(uint64_t n, const uint64_t* data, const uint32_t* counts, const uint8_t* seeds,
-                                    uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) {
+                                    uint8_t* out, uint64_t stride, uint32_t* out_len, int32_t* status) try {
     if (n == 0) return 0;
     if (!data || !counts || !out || !out_len || !status) return fail(ZKP_HIP_E_ARGUMENT, "null pointer argument");
+    { int rcn = check_batch_size(n); if (rcn || (rcn = check_list_total(n, counts))) return rcn; }
     std::vector<uint8_t> fresh;
     if (!seeds) { int rc = fresh_seeds(fresh, n); if (rc) return rc; seeds = fresh.data(); }
     size_t pos = 0;
@@ -1171,7 +1239,7 @@ int zkp_hip_prove_consistency_batch(uint64_t n, const uint64_t* data, const uint
         sha256_host(o + out_len[i] - 32, o + 14, 32ull * counts[i]);
     }
     return any;
-}
+} ZKP_API_CATCH_INT
 
 }  // extern "C"
 

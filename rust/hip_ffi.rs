@@ -67,6 +67,7 @@ extern "C" {
 
     // Groth16 (backend/snark.rs)
     pub fn zkp_hip_groth16_load_key(kind: c_int, pk: *const u8, len: u64) -> c_int;
+    pub fn zkp_hip_groth16_key_info(kind: c_int, wbits: *mut u32, uneven: *mut u32, table_bytes: *mut u64) -> c_int;
     pub fn zkp_hip_groth16_generate_key(kind: c_int, setup_seed: *const u8, pk_out: *mut u8, pk_cap: u64, pk_len: *mut u64, vk_out: *mut u8,
                                         vk_cap: u64, vk_len: *mut u64) -> c_int;
     pub fn zkp_hip_snark_commit_value_batch(n: u64, values: *const u64, out: *mut u8) -> c_int;

@@ -8,7 +8,9 @@
 #include <fstream>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
+#include <sys/resource.h>
 #include <hip/hip_runtime_api.h>
 
 static std::set<std::string> called;
@@ -91,6 +93,12 @@ int main(int argc, char** argv) {
     const auto pk_eq = slurp(gold + "/equality_mimc_pk.bin"), pk_mem = slurp(gold + "/membership_mimc_pk.bin");
     CHECK(!pk_eq.empty() && !pk_mem.empty());
     CHECK(zkp_hip_groth16_load_key(0, pk_eq.data(), pk_eq.size()) == 0 && zkp_hip_groth16_load_key(1, pk_mem.data(), pk_mem.size()) == 0); CALLED(zkp_hip_groth16_load_key);
+    {   // default key tables: radix 2^13 (the knee), unless the environment opted into something else
+        uint32_t wb = 0, un = 9; uint64_t tb = 0;
+        CHECK(zkp_hip_groth16_key_info(0, &wb, &un, &tb) == 0 && wb >= 8 && wb <= 15 && un <= 1 && tb > 0); CALLED(zkp_hip_groth16_key_info);
+        if (!std::getenv("ZKP_HIP_G16_TABLE_BUDGET_MB") && !std::getenv("ZKP_HIP_G16_WBITS")) CHECK(wb <= 13 && un == 0);
+        CHECK(zkp_hip_groth16_key_info(7, &wb, &un, &tb) == ZKP_HIP_E_ARGUMENT);
+    }
     std::vector<uint64_t> ev = {42, 43}; std::vector<uint8_t> com(64);
     CHECK(zkp_hip_snark_commit_value_batch(2, ev.data(), com.data()) == 0 && std::memcmp(com.data(), com.data() + 32, 32) != 0); CALLED(zkp_hip_snark_commit_value_batch);
     std::vector<uint8_t> ep(2 * 298); std::vector<uint32_t> el(2); std::vector<int32_t> es(2);
@@ -164,6 +172,42 @@ int main(int argc, char** argv) {
     }
     zkp_hip_batch_free(B); CALLED(zkp_hip_batch_free);
 
+    // ---- the exception barrier (SURVEY 8b "never abort"; batch.rs:126-130): absurd sizes are argument errors, an allocation failure
+    // inside the library is a negative code with a message -- never an exception through this C++/C frame -- and the library still
+    // proves the same bytes afterwards
+    {
+        zkp_hip_batch* BX = nullptr;
+        CHECK(zkp_hip_batch_stage(1ull << 40, ops.data(), lists.data(), bs.data(), &BX) == ZKP_HIP_E_ARGUMENT && BX == nullptr && std::strstr(zkp_hip_last_error(), "batch too large"));
+        CHECK(zkp_hip_process_batch(1ull << 62, ops.data(), lists.data(), bs.data(), out.data(), cap, off.data(), st.data()) == ZKP_HIP_E_ARGUMENT);
+        CHECK(zkp_hip_prove_range_batch(1ull << 33, v.data(), lo.data(), hi.data(), 64, sd.data(), rp.data(), 1478, rl.data(), rs.data()) == ZKP_HIP_E_ARGUMENT);
+        CHECK(zkp_hip_verify_equality_batch(1ull << 35, ep.data(), 298, el.data(), ok.data()) == ZKP_HIP_E_ARGUMENT);
+        // counts[] that sum past 2^32: rejected before a single list value is read (the lists here hold ten values)
+        std::vector<uint32_t> huge = {0xffffffffu, 0xffffffffu}; std::vector<uint64_t> th2 = {1, 1};
+        std::vector<uint8_t> tp2(2 * 762); std::vector<uint32_t> tl2(2); std::vector<int32_t> ts2(2);
+        CHECK(zkp_hip_prove_threshold_batch(2, lists.data(), huge.data(), th2.data(), 64, sd.data(), tp2.data(), 762, tl2.data(), ts2.data()) == ZKP_HIP_E_ARGUMENT && std::strstr(zkp_hip_last_error(), "value lists too long"));
+        CHECK(zkp_hip_prove_consistency_batch(2, lists.data(), huge.data(), sd.data(), tp2.data(), 762, tl2.data(), ts2.data()) == ZKP_HIP_E_ARGUMENT);
+        std::vector<zkp_hip_op> bad = ops; bad[4].count = 0xffffffffu; bad[5].count = 0xffffffffu;
+        CHECK(zkp_hip_batch_stage(6, bad.data(), lists.data(), bs.data(), &BX) == ZKP_HIP_E_ARGUMENT && BX == nullptr);
+        // address space capped just above what the process holds now: staging 2^21 ops (host vectors of tens of MB, a pinned image of
+        // ~150 MB) cannot be allocated.  The call reports it; then the limit is lifted and the small batch proves bit-exactly again.
+        const uint64_t big = 1ull << 21;
+        std::vector<zkp_hip_op> many(big);
+        for (uint64_t i = 0; i < big; i++) { many[i] = ops[0]; many[i].a = i & 63; }
+        uint64_t vm_kb = 0;
+        { std::ifstream f("/proc/self/status"); std::string w; while (f >> w) if (w == "VmSize:") { f >> vm_kb; break; } }
+        struct rlimit old_lim, lim;
+        CHECK(vm_kb > 0 && getrlimit(RLIMIT_AS, &old_lim) == 0);
+        lim = old_lim; lim.rlim_cur = (vm_kb << 10) + (24ull << 20);
+        CHECK(setrlimit(RLIMIT_AS, &lim) == 0);
+        const int rc_oom = zkp_hip_batch_stage(big, many.data(), lists.data(), nullptr, &BX);
+        const std::string msg_oom = zkp_hip_last_error();
+        CHECK(setrlimit(RLIMIT_AS, &old_lim) == 0);
+        CHECK(rc_oom < 0 && BX == nullptr && !msg_oom.empty());
+        std::fprintf(stderr, "staging 2^21 ops under RLIMIT_AS: rc %d, \"%s\"\n", rc_oom, msg_oom.c_str());
+        std::vector<uint8_t> o4(cap); std::vector<uint64_t> f4(7); std::vector<int32_t> s4(6);
+        CHECK(zkp_hip_process_batch(6, ops.data(), lists.data(), bs.data(), o4.data(), cap, f4.data(), s4.data()) == 0 && f4 == off && std::memcmp(o4.data(), out.data(), off[6]) == 0);
+    }
+
     // ---- profiling counters saw the MSM launches of the calls above
     double kms = 0; uint64_t launches = 0, adds = 0;
     CHECK(zkp_hip_profile_read(&kms, &launches, &adds, 0) == 0 && launches > 0 && adds > 0); CALLED(zkp_hip_profile_read);
@@ -177,10 +221,27 @@ int main(int argc, char** argv) {
     std::vector<uint8_t> out3(cap); std::vector<uint64_t> off3(7); std::vector<int32_t> st3(6);
     CHECK(zkp_hip_process_batch(6, ops.data(), lists.data(), bs.data(), out3.data(), cap, off3.data(), st3.data()) == 0);
     CHECK(off3 == off && std::memcmp(out3.data(), out.data(), off[6]) == 0);   // sharded == unsharded, byte for byte
+    {   // two host threads, each staging / proving / fetching its own batches on the two shards at the same time (the reference calls
+        // process_batch from rayon workers, batch.rs:125-130): every shard's worker takes the two callers' jobs in turn, nobody's job is
+        // lost or answered by the other's completion -- every result equals the single-threaded bytes
+        int bad_runs[2] = {0, 0};
+        auto caller = [&](int t) {
+            for (int it = 0; it < 6; it++) {
+                zkp_hip_batch* Bt = nullptr;
+                std::vector<uint8_t> ot(cap); std::vector<uint64_t> ft(7); std::vector<int32_t> stt(6);
+                if (zkp_hip_batch_stage(6, ops.data(), lists.data(), bs.data(), &Bt) != 0 || zkp_hip_batch_prove_async(Bt) != 0 || zkp_hip_batch_wait(Bt) != 0 ||
+                    zkp_hip_batch_fetch(Bt, ot.data(), cap, ft.data(), stt.data()) != 0 || ft != off || std::memcmp(ot.data(), out.data(), off[6]) != 0) bad_runs[t]++;
+                zkp_hip_batch_free(Bt);
+            }
+        };
+        std::thread ta(caller, 0), tb(caller, 1);
+        ta.join(); tb.join();
+        CHECK(bad_runs[0] == 0 && bad_runs[1] == 0);
+    }
     zkp_hip_shutdown();
     CHECK(zkp_hip_device_count() == 0);
 
-    const size_t expected = 44;                                  // declarations in include/libzkp_hip.h (tests/test_abi.py counts them too)
+    const size_t expected = 45;                                  // declarations in include/libzkp_hip.h (tests/test_abi.py counts them too)
     if (called.size() != expected) { std::fprintf(stderr, "called %zu of %zu entry points\n", called.size(), expected); failures++; }
     if (failures) { std::fprintf(stderr, "abi_call_all: %d failure(s)\n", failures); return 1; }
     std::printf("abi_call_all ok: %zu symbols\n", called.size());

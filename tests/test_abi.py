@@ -77,3 +77,44 @@ def test_product_sources_never_touch_the_oracle():
             if fn.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dp, fn)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libzkp_oracle" not in txt, fn
+
+
+_BARRIER_CHILD = r"""
+import ctypes, resource, sys
+L = ctypes.CDLL(sys.argv[1])
+L.zkp_hip_last_error.restype = ctypes.c_char_p
+u64, u32, vp = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p
+L.zkp_hip_prove_threshold_batch.argtypes = [u64, vp, vp, vp, u32, vp, vp, u64, vp, vp]
+L.zkp_hip_batch_stage.argtypes = [u64, vp, vp, vp, vp]
+dummy = (ctypes.c_uint64 * 8)()
+P = ctypes.addressof(dummy)
+# 1. absurd sizes are argument errors, checked before anything is sized from them (and before any device is looked for)
+out = ctypes.c_void_p()
+assert L.zkp_hip_batch_stage(1 << 40, P, P, P, ctypes.addressof(out)) == -3 and b"batch too large" in L.zkp_hip_last_error()
+assert L.zkp_hip_prove_threshold_batch(1 << 40, P, P, P, 64, P, P, 762, P, P) == -3
+counts = (ctypes.c_uint32 * 2)(0xffffffff, 0xffffffff)
+assert L.zkp_hip_prove_threshold_batch(2, P, ctypes.addressof(counts), P, 64, P, P, 762, P, P) == -3 and b"value lists too long" in L.zkp_hip_last_error()
+# 2. a std::bad_alloc inside the library (seeds = NULL asks for 32 n bytes of fresh randomness; n is the largest accepted batch, all
+#    counts zero so no list value is read) comes back as ZKP_HIP_E_RUNTIME with a message instead of unwinding through the C frame
+n = 1 << 22
+zeros = (ctypes.c_uint32 * n)()
+vm_kb = [int(l.split()[1]) for l in open("/proc/self/status") if l.startswith("VmSize:")][0]
+soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+resource.setrlimit(resource.RLIMIT_AS, ((vm_kb << 10) + (16 << 20), hard))
+rc = L.zkp_hip_prove_threshold_batch(n, P, ctypes.addressof(zeros), P, 64, None, P, 762, P, P)
+msg = L.zkp_hip_last_error()
+resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+assert rc == -1 and b"out of host memory" in msg, (rc, msg)
+# 3. the library is still usable
+assert L.zkp_hip_range_proof_bytes(64) == 1478
+print("barrier ok")
+"""
+
+
+def test_exception_barrier_at_the_c_abi():
+    """per-item status + message, never abort (batch.rs:126-130).  Runs in a child process (it lowers RLIMIT_AS); no compute
+    call is made -- every case returns before a device is needed."""
+    import sys
+    from libzkp_amd import _native
+    r = subprocess.run([sys.executable, "-c", _BARRIER_CHILD, _native.LIB_PATH], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "barrier ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])

@@ -14,4 +14,4 @@ def test_cpp_program_calls_every_entry_point():
     exe = ge.build_abi_caller()
     r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-4000:]
-    assert "abi_call_all ok: 44 symbols" in r.stdout
+    assert "abi_call_all ok: 45 symbols" in r.stdout

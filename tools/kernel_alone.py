@@ -27,6 +27,13 @@ def main():
             if k.startswith("k_g16_build_table") or k.startswith("__amd"):
                 continue                                      # key load / runtime copies: not part of a step
             w.writerow([k, "%.4f" % (tot[k] / cnt[k]), "%.3f" % (cnt[k] / steps), "%.4f" % (tot[k] / steps), cnt[k]])
+    # sidecar: the kernel sources this pass was taken on (bench.py marks the figures stale when they have changed since)
+    import hashlib, json, os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libzkp_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(d)):
+        h.update(fn.encode()); h.update(open(os.path.join(d, fn), "rb").read())
+    json.dump({"csrc_sha16": h.hexdigest()[:16], "source_trace": os.path.basename(src)}, open(out.replace(".csv", ".meta.json"), "w"))
     print("wrote %s: %d kernels over %d steps" % (out, len(tot), steps))
 
 
