@@ -141,7 +141,10 @@ inline MsmLayout make_layout_even(const std::vector<SlotList>& targets, uint32_t
 }
 // n = bits per proof (8, 16, 32, 64): party 0's first n generators of each chain (BulletproofGens::new(n, 2)); slot order
 // = the digit rows bp_steps.h writes for that n
-inline std::vector<SlotList> targets_phase1(uint32_t n = BP_N) {
+// nw / nw64: windows of a full-width scalar / of a 64-bit value at the radix of the tables the launch walks (radix 1024: 26 / 7, the
+// verifier's LDS-streamed tables; radix 2^16: 16 / 5, the prover's HBM-resident tables of edg.h)
+inline std::vector<SlotList> targets_phase1(uint32_t n = BP_N, uint8_t nw = NWIN, uint8_t nw64 = NWIN_U64) {
+    const uint8_t NWIN = nw, NWIN_U64 = nw64;
     SlotList v = {{BASE_B, NWIN_U64}, {BASE_BB, NWIN}}, a = {{BASE_BB, NWIN}}, s = {{BASE_BB, NWIN}};
     for (uint32_t i = 0; i < n; i++) a.push_back({(uint16_t)(BASE_G + i), 1});
     for (uint32_t i = 0; i < n; i++) a.push_back({(uint16_t)(BASE_H + i), 1});
@@ -149,8 +152,9 @@ inline std::vector<SlotList> targets_phase1(uint32_t n = BP_N) {
     for (uint32_t i = 0; i < n; i++) s.push_back({(uint16_t)(BASE_H + i), NWIN});
     return {v, a, s};
 }
-inline std::vector<SlotList> targets_phase2() { SlotList t = {{BASE_B, NWIN}, {BASE_BB, NWIN}}; return {t, t}; }
-inline std::vector<SlotList> targets_round(uint32_t r, uint32_t n = BP_N) {
+inline std::vector<SlotList> targets_phase2(uint8_t nw = NWIN) { SlotList t = {{BASE_B, nw}, {BASE_BB, nw}}; return {t, t}; }
+inline std::vector<SlotList> targets_round(uint32_t r, uint32_t n = BP_N, uint8_t nw = NWIN) {
+    const uint8_t NWIN = nw;
     uint32_t lg = 0; while ((1u << lg) < n) lg++;
     const uint32_t p = lg - 1 - r, k = 1u << p, half = n / 2;
     auto idx = [&](uint32_t rank, uint32_t bit) { return ((rank >> p) << (p + 1)) | (bit << p) | (rank & (k - 1)); };
@@ -161,7 +165,7 @@ inline std::vector<SlotList> targets_round(uint32_t r, uint32_t n = BP_N) {
     for (uint32_t q = 0; q < half; q++) rr.push_back({(uint16_t)(BASE_H + idx(q, 1)), NWIN});
     return {l, rr};
 }
-inline std::vector<SlotList> targets_ctask() { return {SlotList{{BASE_B, NWIN_U64}, {BASE_BB, NWIN}}}; }
+inline std::vector<SlotList> targets_ctask(uint8_t nw = NWIN, uint8_t nw64 = NWIN_U64) { return {SlotList{{BASE_B, nw64}, {BASE_BB, nw}}}; }
 // range-proof verification: one target over all 130 generators (slot index == generator index == digit row)
 inline std::vector<SlotList> targets_verify() {
     SlotList t = {{BASE_B, NWIN}, {BASE_BB, NWIN}};

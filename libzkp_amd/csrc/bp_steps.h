@@ -40,6 +40,7 @@ enum { KIND_RANGE_MIN = 0, KIND_RANGE_MAX, KIND_THRESHOLD, KIND_CONSISTENCY, KIN
 struct BpView {
     uint32_t M;                    // number of proof jobs
     uint32_t n, lg;                // bits per proof (8, 16, 32, 64) and log2 of it: one width per batch
+    uint32_t dig16 = 0;            // 1: MSM digits in signed radix 2^16 (the HBM-resident tables of edg.h: the device prover); 0: radix 1024
     // job description (read-only)
     const uint64_t* v;             // [M] value in [0, 2^64)
     const uint32_t* seed_ix;       // [M] which 32-byte seed
@@ -78,13 +79,19 @@ ZKP_HD inline void st_sc(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows,
     uint32_t* q = p + (size_t)idx * 8 * rows + row;
     ZKP_UNROLL for (int k = 0; k < 8; k++) q[(size_t)k * rows] = s.v[k];
 }
-// store the signed radix-1024 digits of a raw / Montgomery-form scalar: DIGW words per (slot, row), word-major
-ZKP_HD inline void st_digits_raw(uint32_t* d, uint32_t slot, uint32_t row, uint32_t rows, const sc& raw) {
-    uint32_t pk[DIGW]; sc_recode_signed1024(pk, raw);
+// store the signed digits of a raw / Montgomery-form scalar: a row of DIGW words per (slot, row), word-major.  dig16 = 0: radix 1024,
+// 26 digits in 13 words; dig16 = 1: radix 2^16 (sc_recode_signed65536: a word of the scalar is two digits), 16 digits in the first 8 words
+ZKP_HD inline void st_digits_raw(uint32_t* d, uint32_t slot, uint32_t row, uint32_t rows, const sc& raw, uint32_t dig16 = 0) {
     uint32_t* q = d + (size_t)slot * DIGW * rows + row;
+    if (dig16) {
+        uint32_t pk[8]; sc_recode_signed65536(pk, raw);
+        ZKP_UNROLL for (uint32_t k = 0; k < 8; k++) q[(size_t)k * rows] = pk[k];
+        return;
+    }
+    uint32_t pk[DIGW]; sc_recode_signed1024(pk, raw);
     ZKP_UNROLL for (uint32_t k = 0; k < DIGW; k++) q[(size_t)k * rows] = pk[k];
 }
-ZKP_HD inline void st_digits(uint32_t* d, uint32_t slot, uint32_t row, uint32_t rows, const sc& mont) { st_digits_raw(d, slot, row, rows, sc_to_raw(mont)); }
+ZKP_HD inline void st_digits(uint32_t* d, uint32_t slot, uint32_t row, uint32_t rows, const sc& mont, uint32_t dig16 = 0) { st_digits_raw(d, slot, row, rows, sc_to_raw(mont), dig16); }
 ZKP_HD inline int32_t ld_digit(const uint32_t* d, uint32_t srow, uint32_t w, uint32_t row, uint32_t rows) {
     return (int32_t)(int16_t)(d[((size_t)srow * DIGW + (w >> 1)) * rows + row] >> (16 * (w & 1u)));
 }
@@ -111,20 +118,20 @@ ZKP_HD inline void step_tape(const BpView& V, uint32_t slot, uint32_t job) {
         uint32_t w[16]; tape_draw64(w, seed, V.proof_ix[job], slot);
         const sc x = sc_from_wide(w);
         st_sc(V.tape, slot, job, M, x);
-        if (slot == 0) st_digits(V.d1, P1_A + 0, job, M, x);                            // a_blinding * B~
-        else if (slot == 1) st_digits(V.d1, P1_S + 0, job, M, x);                       // s_blinding * B~
-        else if (slot < 2 + n) st_digits(V.d1, P1_S + 1 + (slot - 2), job, M, x);    // s_L[i] * G_i
-        else if (slot < 2 + 2 * n) st_digits(V.d1, P1_S + 1 + n + (slot - 2 - n), job, M, x);  // s_R[i] * H_i
-        else if (slot == 2 + 2 * n) st_digits(V.d2, 1, job, M, x);                   // t1_blinding * B~
-        else st_digits(V.d2, 3, job, M, x);                                             // t2_blinding * B~
+        if (slot == 0) st_digits(V.d1, P1_A + 0, job, M, x, V.dig16);                            // a_blinding * B~
+        else if (slot == 1) st_digits(V.d1, P1_S + 0, job, M, x, V.dig16);                       // s_blinding * B~
+        else if (slot < 2 + n) st_digits(V.d1, P1_S + 1 + (slot - 2), job, M, x, V.dig16);    // s_L[i] * G_i
+        else if (slot < 2 + 2 * n) st_digits(V.d1, P1_S + 1 + n + (slot - 2 - n), job, M, x, V.dig16);  // s_R[i] * H_i
+        else if (slot == 2 + 2 * n) st_digits(V.d2, 1, job, M, x, V.dig16);                   // t1_blinding * B~
+        else st_digits(V.d2, 3, job, M, x, V.dig16);                                             // t2_blinding * B~
     } else {
         sc g = sc_zero();
         if (V.bl_plus[job] >= 0) g = tape_blinding(seed, (uint32_t)V.bl_plus[job]);
         if (V.bl_minus[job] >= 0) g = sc_sub(g, tape_blinding(seed, (uint32_t)V.bl_minus[job]));
         st_sc(V.gamma, 0, job, M, g);
-        st_digits(V.d1, P1_V + 1, job, M, g);
+        st_digits(V.d1, P1_V + 1, job, M, g, V.dig16);
         const uint64_t v = V.v[job];
-        st_digits_raw(V.d1, P1_V + 0, job, M, sc_words((uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0));
+        st_digits_raw(V.d1, P1_V + 0, job, M, sc_words((uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0), V.dig16);
         // A: bit_i * G_i + (bit_i - 1) * H_i  -> single-window digits (+1 / 0 and 0 / -1)
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t bit = (uint32_t)(v >> i) & 1u;
@@ -300,8 +307,8 @@ ZKP_HD inline void step_poly_sum_finish(const BpView& V, uint32_t job, const ScT
     const uint32_t M = V.M;
     const sc t0 = t.a, t2 = t.c, t1 = sc_sub(sc_sub(t.b, t0), t2);
     st_sc(V.scal, SC_T0, job, M, t0); st_sc(V.scal, SC_T1, job, M, t1); st_sc(V.scal, SC_T2, job, M, t2);
-    st_digits(V.d2, 0, job, M, t1);
-    st_digits(V.d2, 2, job, M, t2);
+    st_digits(V.d2, 0, job, M, t1, V.dig16);
+    st_digits(V.d2, 2, job, M, t2, V.dig16);
 }
 ZKP_HD inline void step_poly_sum(const BpView& V, uint32_t job) {
     ScTriple t = step_poly_sum_part(V, 0, job);
@@ -376,8 +383,8 @@ ZKP_HD inline void step_round_prep(const BpView& V, uint32_t r, uint32_t i, uint
     const sc ax = cur_a(x), bx = cur_b(x);
     if (i < 2 * k) { st_sc(abn, x, job, M, ax); st_sc(abn, 64 + x, job, M, bx); }
     const uint32_t bit = (i >> p) & 1u, rank = ((i >> (p + 1)) << p) | (i & (k - 1));
-    st_digits(V.dr, bit ? 1 + rank : V.n + 2 + rank, job, M, sc_mul(ax, g));                    // L's G terms | R's G terms
-    st_digits(V.dr, bit ? V.n + 2 + half + rank : 1 + half + rank, job, M, sc_mul(bx, h));      // R's H terms | L's H terms
+    st_digits(V.dr, bit ? 1 + rank : V.n + 2 + rank, job, M, sc_mul(ax, g), V.dig16);                    // L's G terms | R's G terms
+    st_digits(V.dr, bit ? V.n + 2 + half + rank : 1 + half + rank, job, M, sc_mul(bx, h), V.dig16);      // R's H terms | L's H terms
     if (i < k) {   // here x = i + k
         const sc ai = cur_a(i), bi = cur_b(i);
         st_sc(V.pp, i, job, M, sc_mul(ai, bx));        // a_lo[i] * b_hi[i]
@@ -390,8 +397,8 @@ ZKP_HD inline void step_round_sum(const BpView& V, uint32_t r, uint32_t job) {
     sc cL = sc_zero(), cR = sc_zero();
     for (uint32_t j = 0; j < k; j++) { cL = sc_add(cL, ld_sc(V.pp, j, job, M)); cR = sc_add(cR, ld_sc(V.pp, 32 + j, job, M)); }
     const sc w = ld_sc(V.scal, SC_W, job, M);
-    st_digits(V.dr, 0, job, M, sc_mul(cL, w));
-    st_digits(V.dr, V.n + 1, job, M, sc_mul(cR, w));
+    st_digits(V.dr, 0, job, M, sc_mul(cL, w), V.dig16);
+    st_digits(V.dr, V.n + 1, job, M, sc_mul(cR, w), V.dig16);
 }
 // thread = job
 ZKP_HD inline void step_transcript_round(const BpView& V, uint32_t r, uint32_t job, Strobe& s) {
@@ -422,13 +429,14 @@ struct CtView {
     uint32_t C;
     const uint64_t* v; const uint32_t* seed_ix; const uint32_t* bl_ix; const uint32_t* seeds;
     uint32_t* digits;   // [2][DIGW][C]
+    uint32_t dig16 = 0; // digit radix of the launch that consumes them (BpView::dig16)
 };
 ZKP_HD inline void step_ctask(const CtView& T, uint32_t c) {
     uint32_t seed[8]; const uint32_t* p = T.seeds + (size_t)T.seed_ix[c] * 8;
     ZKP_UNROLL for (int k = 0; k < 8; k++) seed[k] = p[k];
     const uint64_t v = T.v[c];
-    st_digits_raw(T.digits, 0, c, T.C, sc_words((uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0));
-    st_digits(T.digits, 1, c, T.C, tape_blinding(seed, T.bl_ix[c]));
+    st_digits_raw(T.digits, 0, c, T.C, sc_words((uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0), T.dig16);
+    st_digits(T.digits, 1, c, T.C, tape_blinding(seed, T.bl_ix[c]), T.dig16);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -90,7 +90,8 @@ __global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint
 template <class T> constexpr size_t gather_lds_bytes() { return T::GATHER_PREFETCH < 0 ? (size_t)4 * 2 * (T::GATHER_W / 4) * 64 * 16 : 0; }
 template <class T>
 __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, uint32_t ngroups, uint32_t nblocks) {
-    constexpr uint32_t V4 = T::GATHER_W / 4;          // 16-byte pieces of one packed table entry (G1: 64 bytes, G2: 128)
+    constexpr uint32_t V4 = T::GATHER_W / 4;          // 16-byte pieces of one packed table entry (G1: 64 bytes, G2: 128, ed25519: 96)
+    constexpr uint32_t SV4 = T::GATHER_STRIDE / 4;    // ... and of the slot it sits in (ed25519: 128-byte slots, one line per gather)
     const uint32_t tid = threadIdx.x;
     const uint32_t per_xcd = (nblocks + 7) / 8;
     const uint32_t linear = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
@@ -107,7 +108,7 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
     };
     auto fetch = [&](uint4* e, uint32_t slot, uint32_t win, int32_t d) {
         if (d == 0) return;
-        const uint4* src = table4 + ((size_t)m.slot_base[slot] * m.slot_ent + (size_t)(win + (m.uneven && win == 17u ? 1u : 0u)) * m.nent + (uint32_t)((d < 0 ? -d : d) - 1)) * V4;
+        const uint4* src = table4 + ((size_t)m.slot_base[slot] * m.slot_ent + (size_t)(win + (m.uneven && win == 17u ? 1u : 0u)) * m.nent + (uint32_t)((d < 0 ? -d : d) - 1)) * SV4;
         ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) e[k] = src[k];
     };
     if (left == 0) { if (active) T::store(m.partial, chunk, row, m.rows, T::from_gather(acc)); return; }
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
         uint4* const wbuf = gather_lds + (size_t)wave * (2u * V4 * 64u);
         auto dma = [&](uint32_t buf, uint32_t slot, uint32_t win, int32_t dd) {
             if (dd == 0) return;
-            const uint4* src = table4 + ((size_t)m.slot_base[slot] * m.slot_ent + (size_t)(win + (m.uneven && win == 17u ? 1u : 0u)) * m.nent + (uint32_t)((dd < 0 ? -dd : dd) - 1)) * V4;
+            const uint4* src = table4 + ((size_t)m.slot_base[slot] * m.slot_ent + (size_t)(win + (m.uneven && win == 17u ? 1u : 0u)) * m.nent + (uint32_t)((dd < 0 ? -dd : dd) - 1)) * SV4;
             ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) __builtin_amdgcn_global_load_lds(src + k, wbuf + (buf * V4 + k) * 64u, 16, 0, 0);
         };
         uint32_t cb = 0;

@@ -223,6 +223,20 @@ ZKP_HD inline void sc_recode_signed1024(uint32_t packed[13], const sc& raw) {
     }
 }
 
+// signed radix-2^16 digits of a canonical raw scalar (< 2^253): 16 digits in [-32768, 32767], digit j in the half (j & 1) of word j / 2.
+// A digit of 32768 becomes -32768 with a carry; |digit| <= 32768 = entries per window of the HBM-resident tables (edg.h); the top digit (bits 240..252 plus the carry)
+// never overflows.  A 64-bit value occupies digits 0..4 (five windows).
+ZKP_HD inline void sc_recode_signed65536(uint32_t packed[8], const sc& raw) {
+    uint32_t carry = 0;
+    ZKP_UNROLL for (int k = 0; k < 8; k++) {
+        const uint32_t lo = (raw.v[k] & 0xffffu) + carry;               // 0 .. 65536
+        carry = lo > 32767u ? 1u : 0u;
+        const uint32_t hi = (raw.v[k] >> 16) + carry;
+        carry = hi > 32767u ? 1u : 0u;
+        packed[k] = (lo & 0xffffu) | (hi << 16);                        // (hi == 65536 wraps to 0 with the carry set)
+    }
+}
+
 // signed radix-2^WB recoding of a canonical raw scalar: ND digits in [-(2^(WB-1) - 1), 2^(WB-1)], two 16-bit digits per word
 // (WB <= 15; WB * ND must cover the scalar's bit length plus the carry).  WB = 10, ND = 26 is sc_recode_signed1024.
 template <int WB, int ND> ZKP_HD inline void sc_recode_signed(uint32_t* packed, const sc& raw) {

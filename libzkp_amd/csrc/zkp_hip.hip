@@ -33,6 +33,7 @@
 #include "g16_verify_launch.h"
 #include "stark_launch.h"
 #include "bpv_launch.h"
+#include "edg_launch.h"
 #include "../../include/libzkp_hip.h"
 
 // ================================================================================================ kernels
@@ -100,22 +101,29 @@ __global__ void __launch_bounds__(TW, ZKP_LAT_WAVES) k_round_sum(BpView V, uint3
     const uint32_t job = blockIdx.x * TW + threadIdx.x;
     if (job < V.M) step_round_sum(V, r, job);
 }
+// Register budget of the heavy chain kernels (transcripts, partial sums, ristretto encoding), as waves per SIMD: 1 = whatever the compiler
+// likes (k_encode: 273 registers, k_sum_t: 209).  A/B knob (-DZKP_BP_CHAIN_WAVES=3 / 4: at most 168 / 128 registers, so that a wave starts
+// in the space ONE retiring gather wave frees instead of waiting for two).  Measured in round 4 on the mixed batch: 12.26-12.37 ms
+// unconstrained, 12.26 at 3, 12.41 at 4 (range-only batches 2 % slower with either cap): no gain, left at 1.
+#ifndef ZKP_BP_CHAIN_WAVES
+#define ZKP_BP_CHAIN_WAVES 1
+#endif
 // transcript steps: STROBE image of lane t at lds[i * TW + t] (conflict-free: consecutive lanes, consecutive banks)
-__global__ void __launch_bounds__(TW) k_transcript1(BpView V) {
+__global__ void __launch_bounds__(TW, ZKP_BP_CHAIN_WAVES) k_transcript1(BpView V) {
     ZKP_RAISE_PRIO();
     __shared__ uint32_t lds[50 * TW];
     const uint32_t job = blockIdx.x * TW + threadIdx.x;
     Strobe s; s.base = lds + threadIdx.x; s.stride = TW; s.pos = 0; s.pos_begin = 0;
     if (job < V.M) step_transcript1(V, job, s);
 }
-__global__ void __launch_bounds__(TW) k_transcript2(BpView V) {
+__global__ void __launch_bounds__(TW, ZKP_BP_CHAIN_WAVES) k_transcript2(BpView V) {
     ZKP_RAISE_PRIO();
     __shared__ uint32_t lds[50 * TW];
     const uint32_t job = blockIdx.x * TW + threadIdx.x;
     Strobe s; s.base = lds + threadIdx.x; s.stride = TW; s.pos = 0; s.pos_begin = 0;
     if (job < V.M) step_transcript2(V, job, s);
 }
-__global__ void __launch_bounds__(TW) k_transcript_round(BpView V, uint32_t r) {
+__global__ void __launch_bounds__(TW, ZKP_BP_CHAIN_WAVES) k_transcript_round(BpView V, uint32_t r) {
     ZKP_RAISE_PRIO();
     __shared__ uint32_t lds[50 * TW];
     const uint32_t job = blockIdx.x * TW + threadIdx.x;
@@ -126,7 +134,7 @@ __global__ void __launch_bounds__(TW) k_transcript_round(BpView V, uint32_t r) {
 // 3-level tree through LDS -- followed by k_encode (one lane per point, full waves) for the ristretto encoding.
 // (Point addition is associative and the encoding canonical, so the bytes equal reduce_encode_thread's sequential sum,
 // which the host emulation uses.)
-__global__ void __launch_bounds__(TW) k_encode(ReduceView R, const uint32_t* sums) {
+__global__ void __launch_bounds__(TW, ZKP_BP_CHAIN_WAVES) k_encode(ReduceView R, const uint32_t* sums) {
     ZKP_RAISE_PRIO();
     const uint32_t row = blockIdx.x * TW + threadIdx.x, target = blockIdx.y;
     if (row >= R.rows) return;
@@ -159,7 +167,7 @@ struct EdMsm {      // edwards25519 affine-Niels tables, extended-coordinate acc
 
 template __global__ void k_msm_dma<EdMsm>(MsmView, uint32_t, uint32_t);
 static constexpr uint32_t ED_SUM_ROWS = 32, ED_SUM_TB = 256;      // 8 slices per row; one wave per SIMD
-template __global__ void k_sum_t<EdMsm, ED_SUM_ROWS, ED_SUM_TB>(ReduceView, uint32_t*);
+template __global__ void k_sum_t<EdMsm, ED_SUM_ROWS, ED_SUM_TB, ZKP_BP_CHAIN_WAVES>(ReduceView, uint32_t*);
 
 // ================================================================================================ host
 namespace {
@@ -272,11 +280,12 @@ struct DevLayout {
     uint8_t* slot_nwin = nullptr;
     uint32_t nslots = 0, nchunks = 0, ntargets = 0, max_chunk_windows = 0, max_target_chunks = 0;
     uint64_t adds_per_row = 0;   // sum of nwin = point additions per proof in this launch
+    bool gather = false;         // walks the HBM-resident radix-2^16 tables (edg.h: the prover) instead of the LDS-streamed radix-1024 ones (the verifier)
 };
 // candidate chunkings of one launch type: slot-aligned chunks of 32*T windows (T = 1..8) and window-granular "even"
 // chunkings with a given chunk count; the launch picks the one whose grid best fills the resident workgroup slots
 constexpr int MAXT = 8;
-struct LayoutSet { std::vector<DevLayout> cand; uint32_t max_chunks = 0; };
+struct LayoutSet { std::vector<DevLayout> cand; uint32_t max_chunks = 0; bool gather = false; };
 
 struct SubBatch {
     hipStream_t stream = nullptr;
@@ -306,7 +315,9 @@ struct Device {
     int cus_now = 0;                    // CUs the launches being enqueued may use (0 = all): set by the mixed-batch scheduler while it enqueues a variant on CU-masked streams
     std::vector<SubBatch> subm;         // [lane]: Bulletproofs streams + workspace confined to the Bulletproofs CU partition of a mixed batch
     hipStream_t stream = nullptr;
-    uint32_t* d_table = nullptr;
+    uint32_t* d_table = nullptr;        // radix-1024 tables, streamed through LDS (k_msm_dma: the verifier's fixed-base part)
+    uint32_t* d_edg_table = nullptr;    // radix-2^16 tables, gathered per lane from HBM (edg.h: every MSM of the prover)
+    int edg_blocks_per_cu = 3;
     // MSM chunkings: phase 1 and the inner-product rounds depend on the proofs' bit width n = 8 << w (w = 0..3); the
     // 64-bit family is built at init, narrower ones on first use
     struct Family { LayoutSet p1, rd[6]; bool ready = false; };
@@ -496,20 +507,22 @@ void free_layout(DevLayout& D) {
     (void)hipFree(D.slot_base); (void)hipFree(D.chunk_begin); (void)hipFree(D.chunk_win0); (void)hipFree(D.chunk_nwin); (void)hipFree(D.target_chunk_begin); (void)hipFree(D.slot_nwin);
     D = DevLayout();
 }
-int upload_set(LayoutSet& S, const std::vector<SlotList>& targets) {
+int upload_set(LayoutSet& S, const std::vector<SlotList>& targets, bool gather = false) {
+    S.gather = gather;
     uint32_t total = 0; for (auto& t : targets) for (auto& sl : t) total += sl.second;
     auto push = [&](const MsmLayout& L) -> int {
         S.cand.emplace_back();
         int rc = upload_layout(S.cand.back(), L); if (rc) return rc;
+        S.cand.back().gather = gather;
         if (S.cand.back().nchunks > S.max_chunks) S.max_chunks = S.cand.back().nchunks;
         return 0;
     };
     for (int T = 1; T <= MAXT; T++) { int rc = push(make_layout(targets, 32u * T)); if (rc) return rc; }
-    static const uint32_t counts[] = {3, 4, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 36, 40, 42, 48, 51, 56, 64, 72, 80, 85, 96, 112, 128, 144, 160, 192, 224, 256, 320, 384, 448, 512};
+    static const uint32_t counts[] = {3, 4, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 36, 40, 42, 48, 51, 56, 64, 72, 80, 85, 96, 112, 128, 144, 160, 192, 224, 256, 320, 384, 448, 512, 640, 768, 1024};
     for (uint32_t c : counts) { if (c > total || c < targets.size()) continue; int rc = push(make_layout_even(targets, c)); if (rc) return rc; }
     return 0;
 }
-void free_set(LayoutSet& S) { for (auto& d : S.cand) free_layout(d); S.cand.clear(); S.max_chunks = 0; }
+void free_set(LayoutSet& S) { for (auto& d : S.cand) free_layout(d); S.cand.clear(); S.max_chunks = 0; S.gather = false; }
 
 // Chunk size for one launch: the grid is nchunks * ceil(rows/256) workgroups, msm_blocks_per_cu * num_cu of which are
 // resident at a time; cost = (#rounds of resident workgroups) * (windows per workgroup) + the serial partial-sum tail.
@@ -525,13 +538,19 @@ const DevLayout& pick_layout(const LayoutSet& S, uint32_t rows) {
     // granular layout that minimises rounds x (windows per workgroup + per-workgroup overhead) + the partial-sum work
     // that grows with the chunk count; g_fill scales the resident count (benchmarking knob, default 1).
     static const int fill_pct = env_int("ZKP_HIP_BP_FILL", 100);      // tuning knob: size the MSM grids for this percentage of the CUs
-    const double resident = g_fill * (fill_pct / 100.0) * (double)(dev().cus_now ? dev().cus_now : dev().num_cu) * dev().msm_blocks_per_cu;
-    const uint32_t groups = (rows + EdMsm::TB - 1) / EdMsm::TB;
+    // The gather launches (S.gather: the prover) run 256-lane workgroups of four independent waves, edg_blocks_per_cu of them per CU:
+    // no strict rounds, but the same trade -- more chunks fill the chip and shorten a lane's chain of additions, and every chunk is one
+    // more partial point per proof for k_sum_t (a 9-product addition against the 7 of a table step).
+    const uint32_t tb = S.gather ? edg_msm_rows_per_block() : EdMsm::TB;
+    const double per_cu = S.gather ? (double)dev().edg_blocks_per_cu : (double)dev().msm_blocks_per_cu;
+    const double resident = g_fill * (fill_pct / 100.0) * (double)(dev().cus_now ? dev().cus_now : dev().num_cu) * per_cu;
+    const uint32_t groups = (rows + tb - 1) / tb;
     size_t best = MAXT; double best_cost = 1e300;
     for (size_t i = MAXT; i < S.cand.size(); i++) {
         const uint32_t nc = S.cand[i].nchunks;
         const double rounds = std::ceil((double)nc * groups / resident);
-        const double cost = rounds * ((double)S.cand[i].max_chunk_windows + 1.5) + 0.25 * nc / 8.0;
+        const double cost = S.gather ? rounds * ((double)S.cand[i].max_chunk_windows + 1.0) + 1.3 * S.cand[i].max_target_chunks / 8.0
+                                     : rounds * ((double)S.cand[i].max_chunk_windows + 1.5) + 0.25 * nc / 8.0;
         if (cost < best_cost) { best_cost = cost; best = i; }
     }
     return S.cand[best < S.cand.size() ? best : 0];
@@ -542,8 +561,8 @@ int ensure_family(uint32_t lg) {
     Device::Family& F = dev().fam[lg - 3];
     if (F.ready) return 0;
     int rc;
-    if ((rc = upload_set(F.p1, targets_phase1(1u << lg)))) return rc;
-    for (uint32_t r = 0; r < lg; r++) if ((rc = upload_set(F.rd[r], targets_round(r, 1u << lg)))) return rc;
+    if ((rc = upload_set(F.p1, targets_phase1(1u << lg, EDG_NWIN, EDG_NWIN_U64), true))) return rc;
+    for (uint32_t r = 0; r < lg; r++) if ((rc = upload_set(F.rd[r], targets_round(r, 1u << lg, EDG_NWIN), true))) return rc;
     if (F.p1.max_chunks > dev().max_chunks) dev().max_chunks = F.p1.max_chunks;
     for (uint32_t r = 0; r < lg; r++) if (F.rd[r].max_chunks > dev().max_chunks) dev().max_chunks = F.rd[r].max_chunks;
     F.ready = true;
@@ -574,6 +593,60 @@ std::shared_ptr<std::vector<uint32_t>> host_generator_tables() {
 }
 void drop_host_generator_tables() { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); R.host_table.reset(); }
 
+// The prover's tables (edg.h): 130 generators x 16 windows x 32 768 affine-Niels entries in 128-byte slots = 8.7 GB of HBM, computed on the
+// device from the 130 generators (the host derives only those: RFC 9496 one-way map, bp_layout.h) and checked slot against slot before the
+// shard is declared ready.  Takes ~0.1 s.
+// One table per physical GPU in the process: shards registered on the same HIP device share it (like the Groth16 key tables).
+struct EdgTables { std::mutex mu; struct E { int hip_dev; uint32_t* table; int refs; }; std::vector<E> v; };
+EdgTables& edg_tables() { static EdgTables* r = new EdgTables(); return *r; }
+void release_edg_table() {
+    Device& D = dev();
+    if (!D.d_edg_table) return;
+    EdgTables& R = edg_tables();
+    std::lock_guard<std::mutex> lk(R.mu);
+    for (auto& e : R.v) if (e.table == D.d_edg_table && e.refs > 0 && --e.refs == 0) { (void)hipFree(e.table); e.table = nullptr; }
+    D.d_edg_table = nullptr;
+}
+int build_edg_table() {
+    Device& D = dev();
+    if (D.d_edg_table) return 0;
+    EdgTables& R = edg_tables();
+    std::lock_guard<std::mutex> registry_lock(R.mu);          // held across the build: a second shard of this GPU waits and then shares
+    {
+        const uint32_t occ = edg_msm_blocks_per_cu();
+        D.edg_blocks_per_cu = occ ? (int)occ : 3;
+    }
+    for (auto& e : R.v) if (e.hip_dev == D.hip_dev && e.refs > 0) { e.refs++; D.d_edg_table = e.table; return 0; }
+    ge gens[NBASE]; host_generators(gens);
+    std::vector<uint32_t> gw((size_t)NBASE * GE_W);
+    for (uint32_t b = 0; b < NBASE; b++) st_ge(gw.data(), b, 0, 1, gens[b]);
+    uint32_t *d_gens = nullptr, *d_scratch = nullptr; int* d_bad = nullptr;
+    const size_t table_bytes = edg_table_words() * 4, scratch_bytes = edg_build_scratch_words() * 4;
+    if (hipMalloc(&D.d_edg_table, table_bytes) != hipSuccess) {
+        (void)hipGetLastError(); D.d_edg_table = nullptr;
+        char msg[200]; snprintf(msg, sizeof msg, "out of device memory allocating the %llu MB of generator window tables", (unsigned long long)(table_bytes >> 20));
+        return fail(ZKP_HIP_E_RUNTIME, msg);
+    }
+    auto drop = [&]() { (void)hipFree(d_gens); (void)hipFree(d_scratch); (void)hipFree(d_bad); };
+    auto give_up = [&](int code, const std::string& m) { drop(); (void)hipFree(D.d_edg_table); D.d_edg_table = nullptr; return fail(code, m); };
+    hipError_t e = hipMalloc(&d_gens, gw.size() * 4);
+    if (e == hipSuccess) e = hipMalloc(&d_scratch, scratch_bytes);
+    if (e == hipSuccess) e = hipMalloc(&d_bad, sizeof(int));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_gens, gw.data(), gw.size() * 4, hipMemcpyHostToDevice, D.stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, sizeof(int), D.stream);
+    if (e != hipSuccess) return give_up(ZKP_HIP_E_RUNTIME, std::string("generator tables: ") + hipGetErrorString(e));
+    edg_launch_build(d_gens, D.d_edg_table, d_scratch, d_bad, D.stream);
+    int bad = -1;
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, D.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(D.stream);
+    if (e != hipSuccess) return give_up(ZKP_HIP_E_RUNTIME, std::string("generator tables: ") + hipGetErrorString(e));
+    if (bad != 0) { char msg[160]; snprintf(msg, sizeof msg, "generator window tables failed their self-check (%d inconsistent slots)", bad); return give_up(ZKP_HIP_E_RUNTIME, msg); }
+    drop();
+    R.v.push_back({D.hip_dev, D.d_edg_table, 1});
+    return 0;
+}
+
 // brings the bound shard up (caller holds its mutex and has made its HIP device current)
 int init_device() {
     Device& D = dev();
@@ -591,9 +664,10 @@ int init_device() {
         HIP_TRY(hipMemcpy(D.d_table, tab->data(), tab->size() * 4, hipMemcpyHostToDevice));
     }
     int rc;
+    if ((rc = build_edg_table())) return rc;
     D.max_chunks = 0;
-    if ((rc = upload_set(D.p2, targets_phase2()))) return rc;
-    if ((rc = upload_set(D.ct, targets_ctask()))) return rc;
+    if ((rc = upload_set(D.p2, targets_phase2(EDG_NWIN), true))) return rc;
+    if ((rc = upload_set(D.ct, targets_ctask(EDG_NWIN, EDG_NWIN_U64), true))) return rc;
     D.max_chunks = D.p2.max_chunks;
     if ((rc = ensure_family(6))) return rc;
     uint32_t ns = g_subbatches; if (ns <= 1) ns = (uint32_t)env_int("ZKP_HIP_BP_SUBBATCHES", 1); if (ns < 1) ns = 1; if (ns > 8) ns = 8;
@@ -715,6 +789,7 @@ size_t carve(uint8_t* base, uint32_t M, uint32_t C, uint32_t max_chunks, Ws* w) 
     t.J.bl_plus = (int32_t*)take(4ull * M); t.J.bl_minus = (int32_t*)take(4ull * M); t.J.kind = (uint8_t*)take(M);
     t.J.proof_off = (uint64_t*)take(8ull * M); t.J.commit_off = (uint64_t*)take(8ull * M);
     t.J.ct_v = (uint64_t*)take(8ull * C); t.J.ct_seed_ix = (uint32_t*)take(4ull * C); t.J.ct_bl_ix = (uint32_t*)take(4ull * C); t.J.ct_off = (uint64_t*)take(8ull * C);
+    t.V.dig16 = 1; t.T.dig16 = 1;             // the device prover's MSMs walk the radix-2^16 tables (edg.h)
     t.V.M = M; t.V.v = t.J.v; t.V.seed_ix = t.J.seed_ix; t.V.proof_ix = t.J.proof_ix; t.V.bl_plus = t.J.bl_plus; t.V.bl_minus = t.J.bl_minus;
     t.V.kind = t.J.kind; t.V.proof_off = t.J.proof_off; t.V.commit_off = t.J.commit_off;
     t.V.tape = (uint32_t*)take(W * TAPE_SLOTS); t.V.gamma = (uint32_t*)take(W);
@@ -748,17 +823,23 @@ int ensure_workspace(SubBatch& sb, uint32_t M, uint32_t C) {
 int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32_t* partial, hipStream_t st) {
     MsmView m; m.rows = rows; m.nslots = D.nslots; m.nchunks = D.nchunks; m.table = dev().d_table; m.digits = digits;
     m.slot_base = D.slot_base; m.slot_scalar = nullptr; m.slot_nwin = D.slot_nwin; m.chunk_begin = D.chunk_begin; m.chunk_win0 = D.chunk_win0; m.chunk_nwin = D.chunk_nwin; m.partial = partial; m.acc_init = nullptr;
-    const uint32_t ngroups = (rows + EdMsm::TB - 1) / EdMsm::TB, nblocks = D.nchunks * ngroups;
-    const uint32_t grid = ((nblocks + 7) / 8) * 8;
     hipEvent_t e1 = nullptr;
     int rc = prof_begin(dev().prof[0], st, &e1);
     if (rc) return rc;
-    ZKP_TRACED("k_msm_dma<EdMsm>", st, k_msm_dma<EdMsm><<<grid, EdMsm::TB, msm_lds_bytes<EdMsm>(), st>>>(m, ngroups, nblocks));
+    if (D.gather) {
+        m.table = dev().d_edg_table; m.nwin = EDG_NWIN; m.nent = EDG_NENT; m.digw = DIGW; m.slot_ent = EDG_NWIN * EDG_NENT; m.uneven = 0;      // (digit rows keep their 13-word pitch)
+        const uint32_t tb = edg_msm_rows_per_block(), ngroups = (rows + tb - 1) / tb, nblocks = D.nchunks * ngroups;
+        ZKP_TRACED("k_msm_gather<EdGather>", st, edg_launch_msm(m, ngroups, nblocks, st));
+    } else {
+        const uint32_t ngroups = (rows + EdMsm::TB - 1) / EdMsm::TB, nblocks = D.nchunks * ngroups;
+        const uint32_t grid = ((nblocks + 7) / 8) * 8;
+        ZKP_TRACED("k_msm_dma<EdMsm>", st, k_msm_dma<EdMsm><<<grid, EdMsm::TB, msm_lds_bytes<EdMsm>(), st>>>(m, ngroups, nblocks));
+    }
     prof_end(dev().prof[0], st, e1, D.adds_per_row * rows);
     return 0;
 }
 void launch_sum_ed(const ReduceView& R, uint32_t* sums, hipStream_t st) {
-    k_sum_t<EdMsm, ED_SUM_ROWS, ED_SUM_TB><<<dim3((R.rows + ED_SUM_ROWS - 1) / ED_SUM_ROWS, R.ntargets), ED_SUM_TB, 0, st>>>(R, sums);
+    k_sum_t<EdMsm, ED_SUM_ROWS, ED_SUM_TB, ZKP_BP_CHAIN_WAVES><<<dim3((R.rows + ED_SUM_ROWS - 1) / ED_SUM_ROWS, R.ntargets), ED_SUM_TB, 0, st>>>(R, sums);
 }
 int launch_reduce(const DevLayout& D, uint32_t rows, const uint32_t* partial, uint32_t* sums, uint32_t* enc, const uint64_t* out_off, uint8_t* out, hipStream_t st) {
     ReduceView R; R.rows = rows; R.ntargets = D.ntargets; R.partial = partial; R.target_chunk_begin = D.target_chunk_begin;
@@ -1096,6 +1177,7 @@ void zkp_hip_shutdown(void) try {
         }
         d->cus_now = 0;
         (void)hipFree(d->d_table); d->d_table = nullptr;
+        release_edg_table();
         free_set(d->p2); free_set(d->ct);
         for (auto& F : d->fam) { free_set(F.p1); for (auto& s : F.rd) free_set(s); F.ready = false; }
         trace_release();

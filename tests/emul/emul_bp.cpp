@@ -3,6 +3,7 @@
 // Not part of the product library; the product has no host proving path.
 #include "../../libzkp_amd/csrc/bp_layout.h"
 #include "../../libzkp_amd/csrc/bp_verify.h"
+#include "../../libzkp_amd/csrc/edg.h"
 #include <vector>
 #include <cstdlib>
 #include <cstring>
@@ -30,7 +31,69 @@ static void run_reduce(const MsmLayout& L, uint32_t rows, const std::vector<uint
     for (uint32_t t = 0; t < L.ntargets(); t++) for (uint32_t row = 0; row < rows; row++) reduce_encode_thread(r, t, row);
 }
 
+// (e + 1) * 2^(16 w) * G by plain double-and-add, as packed affine-Niels words: the independent route the table builder is checked against
+static void ref_entry(const ge& g, uint32_t w, uint32_t e, uint32_t out[EDG_ENTRY_W]) {
+    ge p = g;
+    for (uint32_t k = 0; k < EDG_WBITS * w; k++) p = ge_dbl(p);
+    ge acc = ge_identity();
+    for (int bit = 15; bit >= 0; bit--) { acc = ge_dbl(acc); if (((e + 1) >> bit) & 1u) acc = ge_add(acc, p); }
+    const fe zi = host_fe_invert(acc.Z);
+    const fe x = fe_mul(acc.X, zi), y = fe_mul(acc.Y, zi);
+    fe_towords(out, fe_add(y, x)); fe_towords(out + 8, fe_sub(y, x)); fe_towords(out + 16, fe_mul(fe_mul(x, y), fe_const_d2()));
+}
+
 extern "C" {
+void emul_sc_recode65536(const uint32_t raw[8], uint32_t out[8]) { sc r; for (int k = 0; k < 8; k++) r.v[k] = raw[k]; sc_recode_signed65536(out, r); }
+
+// Builds window w (all 32 768 slots) of generator `gen` with the device builder's own steps (edg.h: bases, run starts, fill, batched
+// conversion), plus the first slots of window w + 1, runs the builder's self-check over the window, and compares `nsample` slots
+// (first, last, seeded others) with double-and-add.  Returns the number of mismatches of either kind.
+int emul_edg_window(uint32_t gen, uint32_t w, uint32_t nsample, uint32_t seed) {
+    ge gens[NBASE]; host_generators(gens);
+    std::vector<uint32_t> g1(GE_W); st_ge(g1.data(), 0, 0, 1, gens[gen]);
+    std::vector<uint32_t> bases((size_t)EDG_NWIN * GE_W), starts((size_t)EDG_NWIN * EDG_NSEG * GE_W), table((size_t)EDG_NWIN * EDG_NENT * EDG_SLOT_W, 0xDEADBEEFu);
+    edg_step_bases(g1.data(), bases.data(), 0);
+    const uint32_t last = w + 1 < EDG_NWIN ? w + 1 : w;
+    for (uint32_t ww = w; ww <= last; ww++) {
+        edg_step_starts(bases.data(), starts.data(), ww);
+        const uint32_t runs = ww == w ? EDG_NSEG : 1;
+        for (uint32_t s = 0; s < runs; s++) edg_step_fill(bases.data(), starts.data(), table.data(), ww, s);
+        for (size_t g = 0; g < (size_t)runs * EDG_SEG / EDG_INV; g++) edg_step_affine(table.data(), (size_t)ww * EDG_NENT / EDG_INV + g);
+    }
+    int bad = 0;
+    for (uint32_t e = 0; e < EDG_NENT; e++) if (!edg_step_check(table.data(), g1.data(), 0, w, e)) bad++;
+    uint32_t x = seed * 2654435761u + 12345u;
+    for (uint32_t k = 0; k < nsample; k++) {
+        x = x * 1664525u + 1013904223u;
+        const uint32_t e = k == 0 ? 0 : k == 1 ? EDG_NENT - 1 : (x >> 8) % EDG_NENT;
+        uint32_t want[EDG_ENTRY_W]; ref_entry(gens[gen], w, e, want);
+        if (memcmp(want, table.data() + edg_slot(0, w, e), sizeof want) != 0) bad++;
+        for (uint32_t pad = EDG_ENTRY_W; pad < EDG_SLOT_W; pad++) if (table[edg_slot(0, w, e) + pad] != 0) bad++;
+    }
+    // the self-check must also FIND a broken slot
+    table[edg_slot(0, w, 77) + 3] ^= 4u;
+    if (edg_step_check(table.data(), g1.data(), 0, w, 76) && edg_step_check(table.data(), g1.data(), 0, w, 77)) bad++;
+    return bad;
+}
+// one fixed-base term through the gather path's own pieces: sum_w digit_w * 2^(16 w) * G from radix-2^16 digits and entries built on the
+// spot, against k * G by double-and-add (ristretto encodings compared).  Returns 1 when equal.
+int emul_edg_term(uint32_t gen, const uint32_t raw[8], uint32_t enc_out[8]) {
+    ge gens[NBASE]; host_generators(gens);
+    sc r; for (int k = 0; k < 8; k++) r.v[k] = raw[k];
+    uint32_t dig[8]; sc_recode_signed65536(dig, r);
+    ge acc = ge_identity();
+    for (uint32_t w = 0; w < EDG_NWIN; w++) {
+        const int32_t d = (int32_t)(int16_t)(dig[w >> 1] >> (16 * (w & 1u)));
+        if (d == 0) continue;
+        uint32_t entry[EDG_ENTRY_W]; ref_entry(gens[gen], w, (uint32_t)(d < 0 ? -d : d) - 1, entry);
+        acc = edg_accumulate(acc, d, entry);
+    }
+    ge want = ge_identity();
+    for (int bit = 255; bit >= 0; bit--) { want = ge_dbl(want); if ((raw[bit >> 5] >> (bit & 31)) & 1u) want = ge_add(want, gens[gen]); }
+    uint32_t a[8], b[8]; ge_ristretto_encode(a, acc); ge_ristretto_encode(b, want);
+    memcpy(enc_out, a, 32);
+    return memcmp(a, b, 32) == 0;
+}
 void emul_generator(uint32_t idx, uint32_t enc[8]) { ge g[NBASE]; host_generators(g); ge_ristretto_encode(enc, g[idx]); }
 
 // same contract as zkp_hip_prove_range_batch (include/libzkp_hip.h)

@@ -173,3 +173,28 @@ def test_prover_steps_bit_widths(emul, oracle_c):
     out, lens, st = outputs(1)
     one = np.array([1], dtype=np.uint64)
     assert lib.emul_prove_range_batch_bits(U64(1), P(one), P(one), P(one), 12, P(np.zeros(32, dtype=np.uint8)), P(out), U64(1478), P(lens), P(st), 128) == -2
+
+
+def test_hbm_table_builder_and_radix_65536_digits(emul):
+    """The prover's HBM-resident generator tables (libzkp_amd/csrc/edg.h, round 4): the signed radix-2^16 recoding reassembles to the
+    scalar; the device builder's steps produce, for whole windows, the multiples double-and-add gives; its self-check passes on a good
+    window and finds a flipped bit; one fixed-base term assembled from digits and entries equals k * G."""
+    _, lib = emul
+    L = 2**252 + 27742317777372353535851937790883648493
+    rng = np.random.default_rng(11)
+    cases = [0, 1, 32767, 32768, 65535, 65536, 2**64 - 1, 2**253 - 1, L - 1] + [int.from_bytes(rng.bytes(32), "little") % L for _ in range(40)]
+    for k in cases:
+        raw = np.frombuffer(k.to_bytes(32, "little"), dtype=np.uint32).copy()
+        out = np.zeros(8, dtype=np.uint32)
+        lib.emul_sc_recode65536(P(raw), P(out))
+        digs = out.view(np.int16).astype(object)
+        assert sum(int(d) << (16 * i) for i, d in enumerate(digs)) == k
+        assert all(-32768 <= int(d) <= 32767 for d in digs)
+        if k < 2**64:
+            assert not any(int(d) for d in digs[5:])          # a 64-bit value stays inside five windows
+    for gen, w in ((0, 0), (1, 15), (66, 7), (129, 3)):
+        assert lib.emul_edg_window(gen, w, 12, 5 + w) == 0
+    enc = np.zeros(8, dtype=np.uint32)
+    for gen, k in ((0, 1), (2, L - 1), (1, cases[12]), (70, 2**252 + 5), (129, 32768 * (2**16) ** 3)):
+        raw = np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint32).copy()
+        assert lib.emul_edg_term(gen, P(raw), P(enc)) == 1

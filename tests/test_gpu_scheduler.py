@@ -360,5 +360,5 @@ L.zkp_hip_shutdown()
     lines = [json.loads(x) for x in open(trace) if x.strip()]
     assert len(lines) == 2
     names = {r[0] for r in lines[-1]}
-    assert {"k_msm_dma<EdMsm>", "k_msm_gather<G1Msm>", "k_msm_gather<G2Msm>", "k_g16_qap", "k_stark_prove", "k_transcript_round"} <= names
+    assert {"k_msm_gather<EdGather>", "k_msm_gather<G1Msm>", "k_msm_gather<G2Msm>", "k_g16_qap", "k_stark_prove", "k_transcript_round"} <= names
     assert all(r[3] >= r[2] >= 0 for r in lines[-1])
