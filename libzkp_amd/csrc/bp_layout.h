@@ -139,6 +139,28 @@ inline MsmLayout make_layout_even(const std::vector<SlotList>& targets, uint32_t
     }
     return L;
 }
+// The flat step list k_msm_gather walks (msm_kernel.h): for every chunk, in order, one (entry index, digit descriptor) pair per
+// (slot, window) step.  slot_scalar: digit row of each slot (nullptr: row = slot); shape of the table: nent entries per window,
+// slot_ent entries per point, uneven = the 18-window form of radix 2^14 (window 17 starts one nent later), digw words per digit row.
+struct GatherShape { uint32_t nent, slot_ent, uneven, digw; };
+inline bool make_gather_steps(const MsmLayout& L, const uint16_t* slot_scalar, const GatherShape& g, std::vector<uint32_t>& steps, std::vector<uint32_t>& chunk_step0) {
+    steps.clear(); chunk_step0.clear();
+    for (uint32_t c = 0; c < L.nchunks(); c++) {
+        chunk_step0.push_back((uint32_t)(steps.size() / 2));
+        uint32_t s = L.chunk_begin[c], w = L.chunk_win0[c];
+        for (uint32_t left = L.chunk_nwin[c]; left > 0; left--) {
+            const uint64_t first = (uint64_t)L.slot_base[s] * g.slot_ent + (uint64_t)(w + (g.uneven && w == 17u ? 1u : 0u)) * g.nent;
+            const uint64_t word = (uint64_t)(slot_scalar ? slot_scalar[s] : s) * g.digw + w / 2;
+            if (first + g.nent > 0xffffffffull || word > 0x7fffffffull) return false;          // (tables of more than 2^32 entries: not with these circuits)
+            steps.push_back((uint32_t)first); steps.push_back((uint32_t)(word << 1) | (w & 1u));
+            if (++w == L.slot_nwin[s]) { s++; w = 0; }
+        }
+    }
+    chunk_step0.push_back((uint32_t)(steps.size() / 2));
+    for (int pad = 0; pad < 8; pad++) { steps.push_back(0); steps.push_back(0); }              // (the kernel never reads past a chunk's end; slack for wide scalar loads)
+    return true;
+}
+
 // n = bits per proof (8, 16, 32, 64): party 0's first n generators of each chain (BulletproofGens::new(n, 2)); slot order
 // = the digit rows bp_steps.h writes for that n
 // nw / nw64: windows of a full-width scalar / of a 64-bit value at the radix of the tables the launch walks (radix 1024: 26 / 7, the

@@ -186,6 +186,9 @@ struct MsmView {
     uint32_t nwin = 0, nent = 0, digw = 0;      // k_msm_gather only: shape of the table behind `table` (windows per point, entries per
                                                 // window, digit words per scalar) -- a run-time property of the loaded Groth16 key
     uint32_t slot_ent = 0, uneven = 0;          // entries of one point's block; uneven radix (g16_steps.h): window 17 starts one nent later
+    // k_msm_gather's walk of a chunk (bp_layout.h: make_gather_steps): steps[2 t] = index of the first table entry of step t's window,
+    // steps[2 t + 1] = (digit-word row of the step's scalar and window) << 1 | (window & 1); chunk c owns steps chunk_step0[c] .. chunk_step0[c + 1]
+    const uint32_t* steps = nullptr; const uint32_t* chunk_step0 = nullptr;
 };
 ZKP_HD inline void msm_chunk_ref(const MsmView& m, uint32_t chunk, uint32_t row) {
     ge acc = ge_identity();

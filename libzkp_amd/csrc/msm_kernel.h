@@ -88,6 +88,14 @@ __global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint
 // before the addition that consumes them; the digit word that selects them is fetched earlier still.  T::GATHER_PREFETCH = -1: one step
 // of lead through LDS by DMA (no staging registers; gather_lds_bytes<T>() of dynamic LDS per workgroup).
 template <class T> constexpr size_t gather_lds_bytes() { return T::GATHER_PREFETCH < 0 ? (size_t)4 * 2 * (T::GATHER_W / 4) * 64 * 16 : 0; }
+// Round 4: the walk of a chunk is a FLAT STEP LIST read with scalar loads.  Until then every step began with a chain of dependent
+// vector-memory loads of wave-uniform metadata (slot_nwin[s] -> wait -> slot_base[s] -> wait -> digit word -> wait -> the gather could be
+// issued): the values are the same in all 64 lanes, but they came out of 8 / 16-bit arrays, which the compiler reads with
+// global_load_ubyte / _ushort, and each of those queued behind the other waves' scattered gathers in the vector memory pipeline.
+// MsmView::steps holds, for every step of every chunk, (index of the first table entry of the step's window, digit-word row << 1 | which
+// half of the word): two dwords, fetched with s_load_dwordx2 from the scalar cache; chunk_step0[c] .. chunk_step0[c + 1] are chunk c's
+// steps.  The per-lane digit words are loaded two steps before the gather they address is issued, so the only wait left in the loop is
+// the one for the entry that the addition is about to consume, issued GATHER_PREFETCH steps earlier.
 template <class T>
 __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, uint32_t ngroups, uint32_t nblocks) {
     constexpr uint32_t V4 = T::GATHER_W / 4;          // 16-byte pieces of one packed table entry (G1: 64 bytes, G2: 128, ed25519: 96)
@@ -99,97 +107,80 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
     const uint32_t chunk = linear / ngroups, group = linear % ngroups;
     const uint32_t row = group * 256u + tid;
     const bool active = row < m.rows;
-    uint32_t s = m.chunk_begin[chunk], w = m.chunk_win0[chunk], left = m.chunk_nwin[chunk];
+    const uint32_t st0 = m.chunk_step0[chunk], left = m.chunk_step0[chunk + 1] - st0;          // wave-uniform: scalar loads
+    const uint2* const steps = reinterpret_cast<const uint2*>(m.steps) + st0;
     typename T::GAcc acc = T::to_gather(m.acc_init ? T::load(m.acc_init, 0, 0, 1) : T::identity());    // the coordinate system of the loop
     const uint4* const table4 = reinterpret_cast<const uint4*>(m.table);
-    auto digit_word = [&](uint32_t slot, uint32_t win) -> uint32_t {
-        const uint32_t srow = m.slot_scalar ? m.slot_scalar[slot] : slot;
-        return active ? m.digits[((size_t)srow * m.digw + win / T::DIG_PER_WORD) * m.rows + row] : 0u;
-    };
-    auto fetch = [&](uint4* e, uint32_t slot, uint32_t win, int32_t d) {
-        if (d == 0) return;
-        const uint4* src = table4 + ((size_t)m.slot_base[slot] * m.slot_ent + (size_t)(win + (m.uneven && win == 17u ? 1u : 0u)) * m.nent + (uint32_t)((d < 0 ? -d : d) - 1)) * SV4;
-        ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) e[k] = src[k];
-    };
+    auto digit_word = [&](const uint2 ds) -> uint32_t { return active ? m.digits[(size_t)(ds.y >> 1) * m.rows + row] : 0u; };
+#if defined(ZKP_GATHER_EXPERIMENT) && ZKP_GATHER_EXPERIMENT == 1          // measurement builds only (tools/): every gather reads the table's first entry (always an L1 hit)
+    auto entry_of = [&](const uint2, int32_t) -> const uint4* { return table4; };
+#elif defined(ZKP_GATHER_EXPERIMENT) && ZKP_GATHER_EXPERIMENT == 2        // ... every lane of a wave reads the first entry of the step's window (one line per wave-step)
+    auto entry_of = [&](const uint2 ds, int32_t) -> const uint4* { return table4 + (uint64_t)ds.x * SV4; };
+#else
+    auto entry_of = [&](const uint2 ds, int32_t d) -> const uint4* { return table4 + ((uint64_t)ds.x + (uint32_t)((d < 0 ? -d : d) - 1)) * SV4; };
+#endif
     if (left == 0) { if (active) T::store(m.partial, chunk, row, m.rows, T::from_gather(acc)); return; }
-    uint32_t dw = digit_word(s, w);                               // the chunk may start in the middle of a word
-    int32_t d = T::digit(dw, w);
     if constexpr (T::GATHER_PREFETCH < 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        // Entries one step ahead THROUGH LDS (the G2 loop has no registers to spare: 241 VGPRs at two waves per SIMD, so without this the
-        // gather of a step was issued when the step began and its HBM latency -- 2-3 us of a ~10 us addition -- was exposed on every
-        // step).  global_load_lds_dwordx4 moves each lane's 16-byte pieces straight into LDS, no VGPR in between: piece k of the 64 lanes
+        // Entries one step ahead THROUGH LDS (the G2 loop has no registers to spare: 241 VGPRs at two waves per SIMD).
+        // global_load_lds_dwordx4 moves each lane's 16-byte pieces straight into LDS, no VGPR in between: piece k of the 64 lanes
         // of a wave lands as one contiguous KiB (lane l at + 16 l), two buffers per wave, 64 KB per workgroup for 128-byte entries.  A
         // wave only reads what it wrote itself: no barrier, its own vmcnt(0) is the hand-over.
         extern __shared__ uint4 gather_lds[];
         const uint32_t wave = tid >> 6, lane = tid & 63u;
         uint4* const wbuf = gather_lds + (size_t)wave * (2u * V4 * 64u);
-        auto dma = [&](uint32_t buf, uint32_t slot, uint32_t win, int32_t dd) {
+        auto dma = [&](uint32_t buf, const uint2 ds, int32_t dd) {
             if (dd == 0) return;
-            const uint4* src = table4 + ((size_t)m.slot_base[slot] * m.slot_ent + (size_t)(win + (m.uneven && win == 17u ? 1u : 0u)) * m.nent + (uint32_t)((dd < 0 ? -dd : dd) - 1)) * SV4;
+            const uint4* src = entry_of(ds, dd);
             ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) __builtin_amdgcn_global_load_lds(src + k, wbuf + (buf * V4 + k) * 64u, 16, 0, 0);
         };
         uint32_t cb = 0;
-        dma(0, s, w, d);
-        while (left) {
-            const uint32_t nwin = m.slot_nwin[s];
-            uint32_t ns = s, nw = w + 1;
-            if (nw == nwin) { ns = s + 1; nw = 0; }
+        int32_t d = T::digit(digit_word(steps[0]), steps[0].y & 1u);
+        uint32_t q0 = left > 1 ? digit_word(steps[1]) : 0u, q1 = left > 2 ? digit_word(steps[2]) : 0u;      // digit words of steps i + 1, i + 2
+        dma(0, steps[0], d);
+        for (uint32_t i = 0; i < left; i++) {
             int32_t dn = 0;
-            if (left > 1) {
-                if ((nw % T::DIG_PER_WORD) == 0) dw = digit_word(ns, nw);
-                dn = T::digit(dw, nw);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this step's entry (issued a whole addition ago) and the digit word are there
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this step's entry (issued a whole addition ago) and the digit words are there
             uint4 e[V4];
             if (d != 0) { ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) e[k] = wbuf[(cb * V4 + k) * 64u + lane]; }
-            if (left > 1) dma(cb ^ 1u, ns, nw, dn);                   // lands while this step's addition runs
+            if (i + 1 < left) { const uint2 ds = steps[i + 1]; dn = T::digit(q0, ds.y & 1u); dma(cb ^ 1u, ds, dn); }      // lands while this step's addition runs
+            const uint32_t qn = i + 3 < left ? digit_word(steps[i + 3]) : 0u;
             if (d != 0) acc = T::accumulate_entry(acc, d, reinterpret_cast<const uint32_t*>(e));
-            cb ^= 1u; s = ns; w = nw; d = dn; left--;
+            cb ^= 1u; d = dn; q0 = q1; q1 = qn;
         }
         if (active) T::store(m.partial, chunk, row, m.rows, T::from_gather(acc));
         return;
 #endif
-    }
-    uint4 cur[V4], nxt[V4];
-    fetch(cur, s, w, d);
-    if constexpr (T::GATHER_PREFETCH == 2) {
-        // entries TWO steps ahead (the G1 loop has the registers): a wave waits for the slowest of its 64 x 5 scattered loads, and with
-        // one step of lead (~10 us) the tail of the HBM latency distribution still showed (10 % of the launch)
-        auto advance = [&](uint32_t& ps, uint32_t& pw) { if (++pw == m.slot_nwin[ps]) { ps++; pw = 0; } };
-        uint4 nx2[V4];
-        uint32_t s1 = s, w1 = w, s2, w2; int32_t d1 = 0, d2 = 0;
-        if (left > 1) { advance(s1, w1); if ((w1 % T::DIG_PER_WORD) == 0) dw = digit_word(s1, w1); d1 = T::digit(dw, w1); fetch(nxt, s1, w1, d1); }
-        s2 = s1; w2 = w1;
-        while (left) {
-            if (left > 2) { advance(s2, w2); if ((w2 % T::DIG_PER_WORD) == 0) dw = digit_word(s2, w2); d2 = T::digit(dw, w2); fetch(nx2, s2, w2, d2); }
-            if (d != 0) acc = T::accumulate_entry(acc, d, reinterpret_cast<const uint32_t*>(cur));
-            ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) { cur[k] = nxt[k]; nxt[k] = nx2[k]; }
-            d = d1; d1 = d2; d2 = 0; left--;
-        }
     } else {
-        while (left) {
-            const uint32_t nwin = m.slot_nwin[s];
-            uint32_t ns = s, nw = w + 1;
-            if (nw == nwin) { ns = s + 1; nw = 0; }
-            int32_t dn = 0;
-            if (left > 1) {
-                if ((nw % T::DIG_PER_WORD) == 0) dw = digit_word(ns, nw);
-                dn = T::digit(dw, nw);
-                if constexpr (T::GATHER_PREFETCH != 0) fetch(nxt, ns, nw, dn);
-            }
-            if (d != 0) acc = T::accumulate_entry(acc, d, reinterpret_cast<const uint32_t*>(cur));
-            if (left > 1) {
-                if constexpr (T::GATHER_PREFETCH != 0) { ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) cur[k] = nxt[k]; }
-                else fetch(cur, ns, nw, dn);
-            }
-            s = ns; w = nw; d = dn; left--;
+        // Entries LEAD steps ahead in registers (LEAD = 0: fetched when the step begins).  e[0] / dd[0] belong to the step being added,
+        // e[LEAD] is the one in flight; q0 / q1 are the digit words of the next two gathers to be issued.
+        constexpr int LEAD = T::GATHER_PREFETCH;
+        uint4 e[LEAD + 1][V4]; int32_t dd[LEAD + 1];
+        auto fetch = [&](uint4* dst, const uint2 ds, int32_t d) {
+            if (d == 0) return;
+            const uint4* src = entry_of(ds, d);
+            ZKP_UNROLL for (uint32_t k = 0; k < V4; k++) dst[k] = src[k];
+        };
+        uint32_t qpre[LEAD + 2];
+        ZKP_UNROLL for (int k = 0; k < LEAD + 2; k++) qpre[k] = (uint32_t)k < left ? digit_word(steps[k]) : 0u;
+        ZKP_UNROLL for (int k = 0; k < LEAD; k++) {
+            dd[k] = 0;
+            if ((uint32_t)k < left) { const uint2 ds = steps[k]; dd[k] = T::digit(qpre[k], ds.y & 1u); fetch(e[k], ds, dd[k]); }
+        }
+        uint32_t q0 = qpre[LEAD], q1 = qpre[LEAD + 1];
+        for (uint32_t i = 0; i < left; i++) {
+            dd[LEAD] = 0;
+            if (i + LEAD < left) { const uint2 ds = steps[i + LEAD]; dd[LEAD] = T::digit(q0, ds.y & 1u); fetch(e[LEAD], ds, dd[LEAD]); }
+            const uint32_t qn = i + LEAD + 2 < left ? digit_word(steps[i + LEAD + 2]) : 0u;
+            if (dd[0] != 0) acc = T::accumulate_entry(acc, dd[0], reinterpret_cast<const uint32_t*>(e[0]));
+            ZKP_UNROLL for (int k = 0; k < LEAD; k++) { ZKP_UNROLL for (uint32_t v = 0; v < V4; v++) e[k][v] = e[k + 1][v]; dd[k] = dd[k + 1]; }
+            q0 = q1; q1 = qn;
         }
     }
     if (active) T::store(m.partial, chunk, row, m.rows, T::from_gather(acc));
 }
 
-// (Tried in round 2: the same loop over a flat per-chunk step list, software-pipelined three deep so that an iteration only issues
+// (Round 2 had tried a flat per-chunk step list once before, software-pipelined three deep so that an iteration only issues
 // loads -- entry of step i+1, digit word of step i+2, descriptor of step i+3 -- and never waits behind one.  Kernel times were
 // within 1 % of this loop (G1 4.01 vs 4.05 ms, G2 1.70 vs 1.67 ms at 1024 membership rows): the metadata loads at the head of an
 // iteration are not what separates this kernel from the bare addition loop of tools/g1_add_rate.hip)

@@ -31,6 +31,25 @@ ZKP_HD_NOINLINE inline void sha256_block(uint32_t h[8], const uint8_t blk[64]) {
     }
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
+// One padded block given as sixteen big-endian words, compressed from the initial state: fully unrolled with a rolling 16-word
+// schedule, so everything stays in registers (the STARK prover's binding commitment: a fixed 37-byte message, no scratch memory).
+ZKP_HD inline void sha256_one_block_words(uint32_t h[8], const uint32_t m[16]) {
+    uint32_t w[16];
+    ZKP_UNROLL for (int i = 0; i < 16; i++) w[i] = m[i];
+    uint32_t a = 0x6a09e667u, b = 0xbb67ae85u, c = 0x3c6ef372u, d = 0xa54ff53au, e = 0x510e527fu, f = 0x9b05688cu, g = 0x1f83d9abu, hh = 0x5be0cd19u;
+    ZKP_UNROLL for (int i = 0; i < 64; i++) {
+        if (i >= 16) {
+            const uint32_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+            const uint32_t s0 = sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3), s1 = sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10);
+            w[i & 15] = w[i & 15] + s0 + w[(i + 9) & 15] + s1;
+        }
+        const uint32_t t1 = hh + (sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25)) + ((e & f) ^ (~e & g)) + sha256_k(i) + w[i & 15];
+        const uint32_t t2 = (sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] = 0x6a09e667u + a; h[1] = 0xbb67ae85u + b; h[2] = 0x3c6ef372u + c; h[3] = 0xa54ff53au + d;
+    h[4] = 0x510e527fu + e; h[5] = 0x9b05688cu + f; h[6] = 0x1f83d9abu + g; h[7] = 0x5be0cd19u + hh;
+}
 // digest of `len` bytes at `in`
 ZKP_HD_NOINLINE inline void sha256_bytes(uint8_t out[32], const uint8_t* in, uint64_t len) {
     uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};

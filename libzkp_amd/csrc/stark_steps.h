@@ -144,13 +144,18 @@ ZKP_HD inline void blake3_elements(uint32_t out[8], const f128* e, uint32_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------- the binding commitment
-// SHA-256("libzkp_improvement_v1" || u64le(old) || u64le(new))  (utils/commitment.rs:38-50)
+// SHA-256("libzkp_improvement_v1" || u64le(old) || u64le(new))  (utils/commitment.rs:38-50): 37 bytes, one padded block, built in
+// registers -- bytes 0..20 the tag, 21..28 old, 29..36 new (little-endian), 0x80, zeros, the bit length 296 in the last word
 ZKP_HD inline void improvement_commitment(uint8_t out[32], uint64_t oldv, uint64_t newv) {
-    uint8_t msg[37];
-    const char tag[22] = "libzkp_improvement_v1";
-    for (int i = 0; i < 21; i++) msg[i] = (uint8_t)tag[i];
-    for (int i = 0; i < 8; i++) { msg[21 + i] = (uint8_t)(oldv >> (8 * i)); msg[29 + i] = (uint8_t)(newv >> (8 * i)); }
-    sha256_bytes(out, msg, 37);
+    auto byte_at = [&](int i) -> uint32_t {
+        const char tag[22] = "libzkp_improvement_v1";
+        return i < 21 ? (uint32_t)(uint8_t)tag[i] : i < 29 ? (uint32_t)(oldv >> (8 * (i - 21))) & 0xffu : i < 37 ? (uint32_t)(newv >> (8 * (i - 29))) & 0xffu : i == 37 ? 0x80u : 0u;
+    };
+    uint32_t m[16], h[8];
+    ZKP_UNROLL for (int k = 0; k < 16; k++) m[k] = (byte_at(4 * k) << 24) | (byte_at(4 * k + 1) << 16) | (byte_at(4 * k + 2) << 8) | byte_at(4 * k + 3);
+    m[15] = 37 * 8;
+    sha256_one_block_words(h, m);
+    for (int k = 0; k < 8; k++) { out[4 * k] = (uint8_t)(h[k] >> 24); out[4 * k + 1] = (uint8_t)(h[k] >> 16); out[4 * k + 2] = (uint8_t)(h[k] >> 8); out[4 * k + 3] = (uint8_t)h[k]; }
 }
 
 // ---------------------------------------------------------------------------------------------- the prover
@@ -202,33 +207,98 @@ inline void stark_build_constants(StarkConst& C) {
 }
 
 // per-proof shared block (LDS on the GPU)
+// Round 4: nothing of the prover lives in private (scratch) memory any more.  Round 3's kernel passed digests and message blocks to the
+// non-inlined compression function as pointers to per-lane arrays, which puts those arrays in scratch: 976 bytes per lane, and every
+// one of lane 0's ~45 serial compressions paid several round trips to it (VALU active 19 % of the wave's life).  Now a lane hands its
+// chaining value and message block to the ONE copy of the compression through its column of `hio` (word-major: word w of lane l at
+// hio[w * 64 + l], conflict-free), the bookkeeping of the batch Merkle openings sits in `plan_*`, and the three loops that were serial
+// on lane 0 without needing to be -- the 32 query-position draws (32 independent compressions), the copy of ~100 digests and ~60 field
+// elements into the envelope -- are spread over the wave.  What remains serial is the Fiat-Shamir chain itself (~14 compressions).
+constexpr uint32_t STARK_HIO_STRIDE = 64, STARK_PLAN_MAX = 192;
 struct StarkMem {
     f128 t_poly[8], h_poly[8], t_lde[STARK_LDE], h_lde[STARK_LDE], ce[STARK_CE], col[8];
     uint32_t t_leaf[STARK_LDE][8], h_leaf[STARK_LDE][8], t_node[STARK_LDE][8], h_node[STARK_LDE][8];   // node i: children 2i, 2i+1; [1] = root
     uint32_t seed[8]; uint64_t counter;
     f128 coef[3], step, oldv, newv;
+    uint32_t hio[24 * STARK_HIO_STRIDE];                          // hash I/O columns: words 0..7 chaining value / digest, 8..23 message block
+    f128 ood[3], rem[8]; uint32_t rc[8];                          // T(z), T(z g), H(z); the DEEP remainder and its commitment
+    uint64_t mask; uint32_t count;                                // queried positions
+    uint8_t plan_code[STARK_PLAN_MAX]; uint16_t plan_off[STARK_PLAN_MAX];     // opening digests: (0x80 | leaf) or node index, byte offset inside an opening
+    uint32_t plan_n, lists_off[2], val_off[2], tail_off;          // digests per opening; where each opening's node lists, each query block's values and the tail start
+    uint8_t w_idx[32], w_nxt[32], w_cnt[32], w_store[32][6];      // lane 0's bookkeeping of the batch opening
     uint32_t out_len;
     uint8_t out[STARK_MAX_ENVELOPE + 3];
 };
 
-ZKP_HD_NOINLINE inline f128 stark_horner8(const f128* c, const f128& x) {
+// ---- BLAKE3 through a lane's hash I/O column (io = M.hio + lane)
+ZKP_HD_NOINLINE inline void blake3_compress_io(uint32_t* io, uint32_t block_len, uint32_t flags) {
+    uint32_t s[16], m[16];
+    ZKP_UNROLL for (int i = 0; i < 8; i++) s[i] = io[i * STARK_HIO_STRIDE];
+    ZKP_UNROLL for (int i = 0; i < 4; i++) s[8 + i] = blake3_iv(i);
+    s[12] = 0; s[13] = 0; s[14] = block_len; s[15] = flags;
+    ZKP_UNROLL for (int i = 0; i < 16; i++) m[i] = io[(8 + i) * STARK_HIO_STRIDE];
+    ZKP_UNROLL for (int r = 0; r < 7; r++) {
+        ZKP_B3_G(0, 4, 8, 12, m[0], m[1]); ZKP_B3_G(1, 5, 9, 13, m[2], m[3]); ZKP_B3_G(2, 6, 10, 14, m[4], m[5]); ZKP_B3_G(3, 7, 11, 15, m[6], m[7]);
+        ZKP_B3_G(0, 5, 10, 15, m[8], m[9]); ZKP_B3_G(1, 6, 11, 12, m[10], m[11]); ZKP_B3_G(2, 7, 8, 13, m[12], m[13]); ZKP_B3_G(3, 4, 9, 14, m[14], m[15]);
+        if (r < 6) {
+            const uint32_t t[16] = {m[2], m[6], m[3], m[10], m[7], m[0], m[4], m[13], m[1], m[11], m[12], m[5], m[9], m[14], m[15], m[8]};
+            ZKP_UNROLL for (int i = 0; i < 16; i++) m[i] = t[i];
+        }
+    }
+    ZKP_UNROLL for (int i = 0; i < 8; i++) io[i * STARK_HIO_STRIDE] = s[i] ^ s[i + 8];
+}
+ZKP_HD inline void hio_iv(uint32_t* io) { ZKP_UNROLL for (int i = 0; i < 8; i++) io[i * STARK_HIO_STRIDE] = blake3_iv(i); }
+ZKP_HD inline void hio_msg(uint32_t* io, int i, uint32_t v) { io[(8 + i) * STARK_HIO_STRIDE] = v; }
+ZKP_HD inline void hio_msg_zero(uint32_t* io, int from) { for (int i = from; i < 16; i++) hio_msg(io, i, 0u); }
+ZKP_HD inline void hio_digest(uint32_t out[8], const uint32_t* io) { ZKP_UNROLL for (int i = 0; i < 8; i++) out[i] = io[i * STARK_HIO_STRIDE]; }
+ZKP_HD inline void hio_msg_f128(uint32_t* io, int at, const f128& a) {
+    hio_msg(io, at, (uint32_t)a.lo); hio_msg(io, at + 1, (uint32_t)(a.lo >> 32)); hio_msg(io, at + 2, (uint32_t)a.hi); hio_msg(io, at + 3, (uint32_t)(a.hi >> 32));
+}
+// digest (in the column) of a || b, two 8-word digests
+ZKP_HD inline void hio_merge(uint32_t* io, const uint32_t* a, const uint32_t* b) {
+    hio_iv(io);
+    ZKP_UNROLL for (int i = 0; i < 8; i++) { hio_msg(io, i, a[i]); hio_msg(io, 8 + i, b[i]); }
+    blake3_compress_io(io, 64, 11);
+}
+// digest of seed || u64le(v)
+ZKP_HD inline void hio_merge_int(uint32_t* io, const uint32_t* seed, uint64_t v) {
+    hio_iv(io);
+    ZKP_UNROLL for (int i = 0; i < 8; i++) hio_msg(io, i, seed[i]);
+    hio_msg(io, 8, (uint32_t)v); hio_msg(io, 9, (uint32_t)(v >> 32)); hio_msg_zero(io, 10);
+    blake3_compress_io(io, 40, 11);
+}
+// digest of n <= 8 field elements (16 n bytes: one or two blocks of one chunk)
+ZKP_HD inline void hio_elements(uint32_t* io, const f128* e, uint32_t n) {
+    hio_iv(io);
+    const uint32_t nblocks = (n + 3) / 4;
+    for (uint32_t b = 0; b < nblocks; b++) {
+        const uint32_t have = n - 4 * b < 4 ? n - 4 * b : 4;
+        for (uint32_t i = 0; i < 4; i++) { if (i < have) hio_msg_f128(io, 4 * (int)i, e[4 * b + i]); else { hio_msg(io, 4 * (int)i, 0); hio_msg(io, 4 * (int)i + 1, 0); hio_msg(io, 4 * (int)i + 2, 0); hio_msg(io, 4 * (int)i + 3, 0); } }
+        blake3_compress_io(io, 16 * have, (b == 0 ? 1u : 0u) | (b == nblocks - 1 ? 10u : 0u));
+    }
+}
+
+ZKP_HD inline f128 stark_horner8(const f128* c, const f128& x) {
     f128 acc = c[7];
     for (int i = 6; i >= 0; i--) acc = f128_add(f128_mul(acc, x), c[i]);
     return acc;
 }
-// ---- coin (lane 0)
-ZKP_HD inline void coin_reseed(StarkMem& M, const uint32_t d[8]) { uint32_t s[8]; blake3_merge(s, M.seed, d); for (int i = 0; i < 8; i++) M.seed[i] = s[i]; M.counter = 0; }
-ZKP_HD inline void coin_next(StarkMem& M, uint32_t out[8]) { M.counter++; blake3_merge_int(out, M.seed, M.counter); }
-ZKP_HD inline f128 coin_draw(StarkMem& M) {
+// ---- coin (lane 0; io = lane 0's column)
+ZKP_HD inline void coin_reseed(StarkMem& M, uint32_t* io, const uint32_t* d) { hio_merge(io, M.seed, d); hio_digest(M.seed, io); M.counter = 0; }
+ZKP_HD inline void coin_reseed_io(StarkMem& M, uint32_t* io) {             // ... with the digest that sits in the column
+    uint32_t d[8]; hio_digest(d, io);
+    coin_reseed(M, io, d);
+}
+ZKP_HD inline f128 coin_draw(StarkMem& M, uint32_t* io) {
     for (int tries = 0; tries < 1000; tries++) {
-        uint32_t d[8]; coin_next(M, d);
-        f128 v; v.lo = (uint64_t)d[0] | ((uint64_t)d[1] << 32); v.hi = (uint64_t)d[2] | ((uint64_t)d[3] << 32);
+        M.counter++; hio_merge_int(io, M.seed, M.counter);
+        f128 v; v.lo = (uint64_t)io[0] | ((uint64_t)io[STARK_HIO_STRIDE] << 32); v.hi = (uint64_t)io[2 * STARK_HIO_STRIDE] | ((uint64_t)io[3 * STARK_HIO_STRIDE] << 32);
         if (!f128_geq_p(v)) return v;
     }
     return f128_make(0);
 }
 
-// ---- step 0 (lanes 0..7 useful): trace column, its interpolation; lane 0: coin seed
+// ---- step 0 (lanes 0..7 useful): trace column; lane 0: coin seed = BLAKE3(context elements || old || new), 160 bytes = three blocks
 ZKP_HD inline void stark_step_trace(StarkMem& M, const StarkConst& C, uint64_t oldv, uint64_t newv, uint32_t tid, uint32_t nthreads) {
     const f128 o = f128_make(oldv), n = f128_make(newv);
     const f128 step = f128_mul(f128_sub(n, o), C.inv7);
@@ -238,10 +308,15 @@ ZKP_HD inline void stark_step_trace(StarkMem& M, const StarkConst& C, uint64_t o
     }
     if (tid == 0) {
         M.step = step; M.oldv = o; M.newv = n;
-        uint32_t w[40];
-        for (int i = 0; i < 32; i++) w[i] = C.seed_prefix[i];
-        f128_words(w + 32, o); f128_words(w + 36, n);
-        blake3_words(M.seed, w, 40); M.counter = 0;
+        uint32_t* io = M.hio;
+        hio_iv(io);
+        for (int i = 0; i < 16; i++) hio_msg(io, i, C.seed_prefix[i]);
+        blake3_compress_io(io, 64, 1);
+        for (int i = 0; i < 16; i++) hio_msg(io, i, C.seed_prefix[16 + i]);
+        blake3_compress_io(io, 64, 0);
+        hio_msg_f128(io, 0, o); hio_msg_f128(io, 4, n); hio_msg_zero(io, 8);
+        blake3_compress_io(io, 32, 10);
+        hio_digest(M.seed, io); M.counter = 0;
     }
 }
 ZKP_HD inline void stark_step_interp_trace(StarkMem& M, const StarkConst& C, uint32_t tid, uint32_t nthreads) {
@@ -252,27 +327,31 @@ ZKP_HD inline void stark_step_interp_trace(StarkMem& M, const StarkConst& C, uin
     }
 }
 // ---- LDE of one column + row hashes (lane = row)
-ZKP_HD inline void stark_step_lde(const f128* poly, f128* lde, uint32_t (*leaf)[8], const StarkConst& C, uint32_t tid, uint32_t nthreads) {
+ZKP_HD inline void stark_step_lde(StarkMem& M, const f128* poly, f128* lde, uint32_t (*leaf)[8], const StarkConst& C, uint32_t tid, uint32_t nthreads) {
     for (uint32_t i = tid; i < STARK_LDE; i += nthreads) {
         const f128 v = stark_horner8(poly, C.x_lde[i]);
         lde[i] = v;
-        uint32_t w[4]; f128_words(w, v);
-        blake3_words(leaf[i], w, 4);
+        uint32_t* io = M.hio + (i & (STARK_HIO_STRIDE - 1));
+        hio_iv(io); hio_msg_f128(io, 0, v); hio_msg_zero(io, 4);
+        blake3_compress_io(io, 16, 11);
+        hio_digest(leaf[i], io);
     }
 }
 // one Merkle level: nodes [width, 2*width) from the level below (leaves when width == 32)
-ZKP_HD inline void stark_step_merkle_level(uint32_t (*leaf)[8], uint32_t (*node)[8], uint32_t width, uint32_t tid, uint32_t nthreads) {
+ZKP_HD inline void stark_step_merkle_level(StarkMem& M, uint32_t (*leaf)[8], uint32_t (*node)[8], uint32_t width, uint32_t tid, uint32_t nthreads) {
     for (uint32_t j = tid; j < width; j += nthreads) {
         const uint32_t i = width + j;
-        if (width == STARK_LDE / 2) blake3_merge(node[i], leaf[2 * j], leaf[2 * j + 1]);
-        else blake3_merge(node[i], node[2 * i], node[2 * i + 1]);
+        uint32_t* io = M.hio + (j & (STARK_HIO_STRIDE - 1));
+        if (width == STARK_LDE / 2) hio_merge(io, leaf[2 * j], leaf[2 * j + 1]);
+        else hio_merge(io, node[2 * i], node[2 * i + 1]);
+        hio_digest(node[i], io);
     }
 }
 // ---- lane 0: reseed with the trace root, draw the constraint composition coefficients
 ZKP_HD inline void stark_step_coefficients(StarkMem& M, uint32_t tid) {
     if (tid != 0) return;
-    coin_reseed(M, M.t_node[1]);
-    for (int i = 0; i < 3; i++) M.coef[i] = coin_draw(M);
+    coin_reseed(M, M.hio, M.t_node[1]);
+    for (int i = 0; i < 3; i++) M.coef[i] = coin_draw(M, M.hio);
 }
 // ---- lanes 0..15: combined constraint evaluations on the constraint-evaluation coset
 ZKP_HD inline void stark_step_constraints(StarkMem& M, const StarkConst& C, uint32_t tid, uint32_t nthreads) {
@@ -294,7 +373,7 @@ ZKP_HD inline void stark_step_interp_constraints(StarkMem& M, const StarkConst& 
     }
 }
 
-// ---- serialisation helpers (lane 0)
+// ---- serialisation helpers
 struct StarkWriter {
     uint8_t* p; uint32_t n;
     ZKP_HD void u8(uint32_t v) { p[n++] = (uint8_t)v; }
@@ -304,92 +383,150 @@ struct StarkWriter {
     ZKP_HD void words(const uint32_t* w, uint32_t k) { for (uint32_t i = 0; i < k; i++) { u8(w[i]); u8(w[i] >> 8); u8(w[i] >> 16); u8(w[i] >> 24); } }
     ZKP_HD void el(const f128& a) { uint32_t w[4]; f128_words(w, a); words(w, 4); }
 };
-// queried values + batch Merkle opening of one commitment (positions = set bits of `mask`, ascending)
-ZKP_HD_NOINLINE inline void stark_write_queries(StarkWriter& W, const f128* lde, uint32_t (*leaf)[8], uint32_t (*node)[8], uint64_t mask, uint32_t count) {
-    W.vint(16 * count);
-    for (uint32_t i = 0; i < STARK_LDE; i++) if ((mask >> i) & 1) W.el(lde[i]);
-    // batch opening: one node list per queried sibling pair
-    uint8_t idx[32], nxt[32]; uint8_t cnt[32]; uint8_t store[32][6];   // per list: up to 1 leaf + 5 internal siblings, as (level, index) codes
+ZKP_HD inline uint32_t stark_vint_len(uint32_t v) { return v < 128 ? 1u : v < 16384 ? 2u : 3u; }
+ZKP_HD inline void stark_put_word(uint8_t* p, uint32_t w) { p[0] = (uint8_t)w; p[1] = (uint8_t)(w >> 8); p[2] = (uint8_t)(w >> 16); p[3] = (uint8_t)(w >> 24); }
+ZKP_HD inline void stark_put_el(uint8_t* p, const f128& a) { stark_put_word(p, (uint32_t)a.lo); stark_put_word(p + 4, (uint32_t)(a.lo >> 32)); stark_put_word(p + 8, (uint32_t)a.hi); stark_put_word(p + 12, (uint32_t)(a.hi >> 32)); }
+
+// ---- lane 0: the Fiat-Shamir chain after the constraint commitment, down to the seed the query positions are drawn from
+ZKP_HD inline void stark_step_chain(StarkMem& M, const StarkConst& C, uint32_t tid) {
+    if (tid != 0) return;
+    uint32_t* io = M.hio;
+    coin_reseed(M, io, M.h_node[1]);
+    const f128 z = coin_draw(M, io), zg = f128_mul(z, C.g);
+    const f128 tz = stark_horner8(M.t_poly, z), tzg = stark_horner8(M.t_poly, zg);
+    M.ood[0] = tz; M.ood[1] = tzg;
+    hio_elements(io, M.ood, 2); coin_reseed_io(M, io);
+    const f128 hz = stark_horner8(M.h_poly, z);
+    M.ood[2] = hz;
+    hio_elements(io, M.ood + 2, 1); coin_reseed_io(M, io);
+    const f128 dc0 = coin_draw(M, io), dc1 = coin_draw(M, io);
+    // DEEP polynomial: dc0 * ((T - T(z))/(x - z) + (T - T(zg))/(x - zg)) + dc1 * (H - H(z))/(x - z), by synthetic division
+    {
+        f128 c1 = f128_make(0), c2 = f128_make(0), c3 = f128_make(0);
+        M.rem[7] = f128_make(0);
+        for (int i = 7; i >= 1; i--) {
+            c1 = f128_add(M.t_poly[i], f128_mul(c1, z));
+            c2 = f128_add(M.t_poly[i], f128_mul(c2, zg));
+            c3 = f128_add(M.h_poly[i], f128_mul(c3, z));
+            M.rem[i - 1] = f128_add(f128_mul(dc0, f128_add(c1, c2)), f128_mul(dc1, c3));
+        }
+    }
+    hio_elements(io, M.rem, 8); hio_digest(M.rc, io);
+    coin_reseed_io(M, io);
+    // query positions are drawn from seed' = merge_int(seed, nonce 0)
+    hio_merge_int(io, M.seed, 0); hio_digest(M.seed, io); M.counter = 0;
+    M.mask = 0;
+}
+// ---- lanes 0..31: the query positions, 32 independent draws (coin counter q + 1)
+ZKP_HD inline void stark_step_queries(StarkMem& M, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t q = tid; q < STARK_QUERIES; q += nthreads) {
+        uint32_t* io = M.hio + q;
+        hio_merge_int(io, M.seed, (uint64_t)q + 1);
+        const uint64_t bit = 1ull << (io[0] & (STARK_LDE - 1));
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(reinterpret_cast<unsigned long long*>(&M.mask), (unsigned long long)bit);
+#else
+        M.mask |= bit;
+#endif
+    }
+}
+ZKP_HD inline uint32_t stark_popcount64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll(x);
+#else
+    return (uint32_t)__builtin_popcountll(x);
+#endif
+}
+// ---- lane 0: lays the envelope out -- [2][5][u32 payload][u32 32][old][new][context][count][u16 96][three roots][trace queries]
+// [constraint queries][out-of-domain frame][remainder][tail][commitment] -- writes every byte that is not a field element or a digest,
+// and lists, once for both openings (same positions, same tree shape), which digests a batch opening carries and where they go.
+ZKP_HD inline void stark_step_plan(StarkMem& M, const StarkConst& C, uint64_t oldv, uint64_t newv, uint32_t tid) {
+    if (tid != 0) return;
+    const uint64_t mask = M.mask;
+    const uint32_t count = stark_popcount64(mask);
+    M.count = count;
+    // which digests: one node list per queried sibling pair (leaf codes 0x80 | index, internal nodes by index)
     uint32_t npairs = 0;
     for (uint32_t pr = 0; pr < STARK_LDE; pr += 2) {
         const uint32_t a = (uint32_t)(mask >> pr) & 1, b = (uint32_t)(mask >> (pr + 1)) & 1;
         if (!(a | b)) continue;
-        cnt[npairs] = 0;
-        if (!a) store[npairs][cnt[npairs]++] = (uint8_t)(0x80 | pr);             // leaf code: 0x80 | leaf index
-        if (!b) store[npairs][cnt[npairs]++] = (uint8_t)(0x80 | (pr + 1));
-        idx[npairs] = (uint8_t)((pr + STARK_LDE) >> 1);
+        M.w_cnt[npairs] = 0;
+        if (!a) M.w_store[npairs][M.w_cnt[npairs]++] = (uint8_t)(0x80 | pr);
+        if (!b) M.w_store[npairs][M.w_cnt[npairs]++] = (uint8_t)(0x80 | (pr + 1));
+        M.w_idx[npairs] = (uint8_t)((pr + STARK_LDE) >> 1);
         npairs++;
     }
     uint32_t ncur = npairs;
     for (uint32_t level = 1; level < STARK_DEPTH; level++) {
         uint32_t nn = 0, i = 0;
         while (i < ncur) {
-            const uint32_t sib = idx[i] ^ 1u;
-            if (i + 1 < ncur && idx[i + 1] == sib) i++;
-            else store[i][cnt[i]++] = (uint8_t)sib;                               // internal node code: its index (< 64)
-            nxt[nn++] = (uint8_t)(sib >> 1);
+            const uint32_t sib = M.w_idx[i] ^ 1u;
+            if (i + 1 < ncur && M.w_idx[i + 1] == sib) i++;
+            else M.w_store[i][M.w_cnt[i]++] = (uint8_t)sib;
+            M.w_nxt[nn++] = (uint8_t)(sib >> 1);
             i++;
         }
-        for (uint32_t k = 0; k < nn; k++) idx[k] = nxt[k];
+        for (uint32_t k = 0; k < nn; k++) M.w_idx[k] = M.w_nxt[k];
         ncur = nn;
     }
-    uint32_t total = 0; for (uint32_t k = 0; k < npairs; k++) total += cnt[k];
-    W.vint(1 + 1 + npairs + 32 * total);                                          // depth byte, list count (npairs <= 32: one byte), list headers, digests
-    W.u8(STARK_DEPTH); W.vint(npairs);
-    for (uint32_t k = 0; k < npairs; k++) {
-        W.u8(cnt[k]);
-        for (uint32_t j = 0; j < cnt[k]; j++) { const uint32_t c = store[k][j]; W.words((c & 0x80) ? leaf[c & 0x7F] : node[c], 8); }
-    }
-}
-// ---- lane 0: everything after the constraint commitment
-ZKP_HD_NOINLINE inline void stark_step_finish(StarkMem& M, const StarkConst& C, uint64_t oldv, uint64_t newv, uint32_t tid) {
-    if (tid != 0) return;
-    coin_reseed(M, M.h_node[1]);
-    const f128 z = coin_draw(M), zg = f128_mul(z, C.g);
-    const f128 tz = stark_horner8(M.t_poly, z), tzg = stark_horner8(M.t_poly, zg);
-    uint32_t d[8];
-    { const f128 e[2] = {tz, tzg}; blake3_elements(d, e, 2); coin_reseed(M, d); }
-    const f128 hz = stark_horner8(M.h_poly, z);
-    blake3_elements(d, &hz, 1); coin_reseed(M, d);
-    const f128 dc0 = coin_draw(M), dc1 = coin_draw(M);
-    // DEEP polynomial: dc0 * ((T - T(z))/(x - z) + (T - T(zg))/(x - zg)) + dc1 * (H - H(z))/(x - z), by synthetic division
-    f128 rem[8];
-    {
-        f128 c1 = f128_make(0), c2 = f128_make(0), c3 = f128_make(0);
-        rem[7] = f128_make(0);
-        for (int i = 7; i >= 1; i--) {
-            c1 = f128_add(M.t_poly[i], f128_mul(c1, z));
-            c2 = f128_add(M.t_poly[i], f128_mul(c2, zg));
-            c3 = f128_add(M.h_poly[i], f128_mul(c3, z));
-            rem[i - 1] = f128_add(f128_mul(dc0, f128_add(c1, c2)), f128_mul(dc1, c3));
-        }
-    }
-    uint32_t rc[8]; blake3_elements(rc, rem, 8);
-    coin_reseed(M, rc);
-    // query positions: nonce 0, 32 draws of 6 bits, sorted + deduplicated = a 64-bit set
-    { uint32_t s[8]; blake3_merge_int(s, M.seed, 0); for (int i = 0; i < 8; i++) M.seed[i] = s[i]; M.counter = 0; }
-    uint64_t mask = 0;
-    for (uint32_t q = 0; q < STARK_QUERIES; q++) { coin_next(M, d); mask |= 1ull << (d[0] & (STARK_LDE - 1)); }
-    uint32_t count = 0; for (uint32_t i = 0; i < STARK_LDE; i++) count += (uint32_t)(mask >> i) & 1;
-    // envelope: [2][5][u32 payload][u32 32][old][new][stark proof][commitment]
+    uint32_t total = 0; for (uint32_t k = 0; k < npairs; k++) total += M.w_cnt[k];
+    const uint32_t open_len = 1 + 1 + npairs + 32 * total;            // depth byte, list count (npairs <= 32: one byte), list headers, digests
+    const uint32_t block = stark_vint_len(16 * count) + 16 * count + stark_vint_len(open_len) + open_len;
     StarkWriter W{M.out, 0};
     W.u8(2); W.u8(5); W.n += 4; W.u8(32); W.u8(0); W.u8(0); W.u8(0);
     W.u64(oldv); W.u64(newv);
     for (int i = 0; i < 28; i++) W.u8(C.context_bytes[i]);
     W.u8(count);
-    W.u16(96); W.words(M.t_node[1], 8); W.words(M.h_node[1], 8); W.words(rc, 8);
-    stark_write_queries(W, M.t_lde, M.t_leaf, M.t_node, mask, count);
-    stark_write_queries(W, M.h_lde, M.h_leaf, M.h_node, mask, count);
-    W.u16(33); W.u8(2); W.el(tz); W.el(tzg);
-    W.u16(16); W.el(hz);
-    W.u8(0); W.u16(128); for (int i = 0; i < 8; i++) W.el(rem[i]);
+    W.u16(96); W.n += 96;                                              // the three roots: stark_step_emit
+    uint32_t e = 0;
+    for (uint32_t tree = 0; tree < 2; tree++) {
+        W.vint(16 * count); M.val_off[tree] = W.n; W.n += 16 * count;
+        W.vint(open_len); W.u8(STARK_DEPTH); W.vint(npairs);
+        M.lists_off[tree] = W.n;
+        uint32_t rel = 0;
+        for (uint32_t k = 0; k < npairs; k++) {
+            W.p[M.lists_off[tree] + rel] = M.w_cnt[k]; rel++;
+            for (uint32_t j = 0; j < M.w_cnt[k]; j++) { if (tree == 0) { M.plan_code[e] = M.w_store[k][j]; M.plan_off[e] = (uint16_t)rel; e++; } rel += 32; }
+        }
+        W.n += rel;
+    }
+    (void)block;
+    M.plan_n = e;
+    M.tail_off = W.n;
+    W.u16(33); W.u8(2); W.n += 32;                                     // T(z), T(z g)
+    W.u16(16); W.n += 16;                                              // H(z)
+    W.u8(0); W.u16(128); W.n += 128;                                   // the remainder's eight coefficients
     W.u8(1);
     W.u64(0); W.u8(0);
     const uint32_t payload = W.n - 10;
     M.out[2] = (uint8_t)payload; M.out[3] = (uint8_t)(payload >> 8); M.out[4] = (uint8_t)(payload >> 16); M.out[5] = (uint8_t)(payload >> 24);
-    uint8_t cm[32]; improvement_commitment(cm, oldv, newv);
-    for (int i = 0; i < 32; i++) W.u8(cm[i]);
-    M.out_len = W.n;
+    improvement_commitment(M.out + W.n, oldv, newv);
+    M.out_len = W.n + 32;
+}
+// ---- all lanes: field elements and digests into the places the plan gave them
+ZKP_HD inline void stark_step_emit(StarkMem& M, uint32_t tid, uint32_t nthreads) {
+    const uint64_t mask = M.mask;
+    for (uint32_t i = tid; i < STARK_LDE; i += nthreads) {
+        if (!((mask >> i) & 1)) continue;
+        const uint32_t rank = stark_popcount64(mask & ((1ull << i) - 1));
+        stark_put_el(M.out + M.val_off[0] + 16 * rank, M.t_lde[i]);
+        stark_put_el(M.out + M.val_off[1] + 16 * rank, M.h_lde[i]);
+    }
+    const uint32_t nw = M.plan_n * 8;
+    for (uint32_t t = tid; t < 2 * nw; t += nthreads) {
+        const uint32_t tree = t >= nw ? 1u : 0u, r = t - tree * nw, e = r >> 3, w = r & 7u;
+        const uint32_t c = M.plan_code[e];
+        const uint32_t v = tree == 0 ? ((c & 0x80) ? M.t_leaf[c & 0x7F][w] : M.t_node[c][w]) : ((c & 0x80) ? M.h_leaf[c & 0x7F][w] : M.h_node[c][w]);
+        stark_put_word(M.out + M.lists_off[tree] + M.plan_off[e] + 4 * w, v);
+    }
+    for (uint32_t t = tid; t < 24; t += nthreads) {                    // the three roots
+        const uint32_t v = t < 8 ? M.t_node[1][t] : t < 16 ? M.h_node[1][t - 8] : M.rc[t - 16];
+        stark_put_word(M.out + 57 + 4 * t, v);
+    }
+    for (uint32_t t = tid; t < 11; t += nthreads) {                    // out-of-domain frame and remainder
+        const uint32_t at = M.tail_off + (t < 2 ? 3 + 16 * t : t == 2 ? 3 + 32 + 2 : 3 + 32 + 2 + 16 + 3 + 16 * (t - 3));
+        stark_put_el(M.out + at, t < 3 ? M.ood[t] : M.rem[t - 3]);
+    }
 }
 
 // the whole proof; host emulation runs it with nthreads = 1 and a no-op barrier
@@ -397,14 +534,17 @@ template <class Sync>
 ZKP_HD inline void stark_prove(StarkMem& M, const StarkConst& C, uint64_t oldv, uint64_t newv, uint32_t tid, uint32_t nthreads, Sync sync) {
     stark_step_trace(M, C, oldv, newv, tid, nthreads); sync();
     stark_step_interp_trace(M, C, tid, nthreads); sync();
-    stark_step_lde(M.t_poly, M.t_lde, M.t_leaf, C, tid, nthreads); sync();
-    for (uint32_t w = STARK_LDE / 2; w >= 1; w >>= 1) { stark_step_merkle_level(M.t_leaf, M.t_node, w, tid, nthreads); sync(); }
+    stark_step_lde(M, M.t_poly, M.t_lde, M.t_leaf, C, tid, nthreads); sync();
+    for (uint32_t w = STARK_LDE / 2; w >= 1; w >>= 1) { stark_step_merkle_level(M, M.t_leaf, M.t_node, w, tid, nthreads); sync(); }
     stark_step_coefficients(M, tid); sync();
     stark_step_constraints(M, C, tid, nthreads); sync();
     stark_step_interp_constraints(M, C, tid, nthreads); sync();
-    stark_step_lde(M.h_poly, M.h_lde, M.h_leaf, C, tid, nthreads); sync();
-    for (uint32_t w = STARK_LDE / 2; w >= 1; w >>= 1) { stark_step_merkle_level(M.h_leaf, M.h_node, w, tid, nthreads); sync(); }
-    stark_step_finish(M, C, oldv, newv, tid); sync();
+    stark_step_lde(M, M.h_poly, M.h_lde, M.h_leaf, C, tid, nthreads); sync();
+    for (uint32_t w = STARK_LDE / 2; w >= 1; w >>= 1) { stark_step_merkle_level(M, M.h_leaf, M.h_node, w, tid, nthreads); sync(); }
+    stark_step_chain(M, C, tid); sync();
+    stark_step_queries(M, tid, nthreads); sync();
+    stark_step_plan(M, C, oldv, newv, tid); sync();
+    stark_step_emit(M, tid, nthreads); sync();
 }
 
 // ---------------------------------------------------------------------------------------------- the verifier

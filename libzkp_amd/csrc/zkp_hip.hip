@@ -281,6 +281,7 @@ struct DevLayout {
     uint32_t nslots = 0, nchunks = 0, ntargets = 0, max_chunk_windows = 0, max_target_chunks = 0;
     uint64_t adds_per_row = 0;   // sum of nwin = point additions per proof in this launch
     bool gather = false;         // walks the HBM-resident radix-2^16 tables (edg.h: the prover) instead of the LDS-streamed radix-1024 ones (the verifier)
+    uint32_t *steps = nullptr, *chunk_step0 = nullptr;      // k_msm_gather's flat step list (make_gather_steps); only for layouts that kernel walks
 };
 // candidate chunkings of one launch type: slot-aligned chunks of 32*T windows (T = 1..8) and window-granular "even"
 // chunkings with a given chunk count; the launch picks the one whose grid best fills the resident workgroup slots
@@ -479,7 +480,7 @@ void trace_release() {
     delete T; dev().trace = nullptr;
 }
 
-int upload_layout(DevLayout& D, const MsmLayout& L) {
+int upload_layout(DevLayout& D, const MsmLayout& L, const GatherShape* shape = nullptr, const uint16_t* slot_scalar = nullptr) {
     D.nslots = L.nslots(); D.nchunks = L.nchunks(); D.ntargets = L.ntargets();
     D.adds_per_row = 0; for (uint8_t x : L.slot_nwin) D.adds_per_row += x;
     D.max_chunk_windows = 0;
@@ -501,10 +502,18 @@ int upload_layout(DevLayout& D, const MsmLayout& L) {
     HIP_TRY(hipMemcpy(D.chunk_nwin, L.chunk_nwin.data(), L.chunk_nwin.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(D.target_chunk_begin, L.target_chunk_begin.data(), L.target_chunk_begin.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(D.slot_nwin, L.slot_nwin.data(), L.slot_nwin.size(), hipMemcpyHostToDevice));
+    if (shape) {
+        std::vector<uint32_t> steps, step0;
+        if (!make_gather_steps(L, slot_scalar, *shape, steps, step0)) return fail(ZKP_HIP_E_UNSUPPORTED, "window tables of more than 2^32 entries");
+        HIP_TRY(hipMalloc(&D.steps, steps.size() * 4)); HIP_TRY(hipMalloc(&D.chunk_step0, step0.size() * 4));
+        HIP_TRY(hipMemcpy(D.steps, steps.data(), steps.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(D.chunk_step0, step0.data(), step0.size() * 4, hipMemcpyHostToDevice));
+    }
     return 0;
 }
 void free_layout(DevLayout& D) {
     (void)hipFree(D.slot_base); (void)hipFree(D.chunk_begin); (void)hipFree(D.chunk_win0); (void)hipFree(D.chunk_nwin); (void)hipFree(D.target_chunk_begin); (void)hipFree(D.slot_nwin);
+    (void)hipFree(D.steps); (void)hipFree(D.chunk_step0);
     D = DevLayout();
 }
 int upload_set(LayoutSet& S, const std::vector<SlotList>& targets, bool gather = false) {
@@ -512,7 +521,8 @@ int upload_set(LayoutSet& S, const std::vector<SlotList>& targets, bool gather =
     uint32_t total = 0; for (auto& t : targets) for (auto& sl : t) total += sl.second;
     auto push = [&](const MsmLayout& L) -> int {
         S.cand.emplace_back();
-        int rc = upload_layout(S.cand.back(), L); if (rc) return rc;
+        const GatherShape edg_shape{EDG_NENT, EDG_NWIN * EDG_NENT, 0u, DIGW};      // (digit rows keep their 13-word pitch)
+        int rc = upload_layout(S.cand.back(), L, gather ? &edg_shape : nullptr); if (rc) return rc;
         S.cand.back().gather = gather;
         if (S.cand.back().nchunks > S.max_chunks) S.max_chunks = S.cand.back().nchunks;
         return 0;
@@ -827,7 +837,8 @@ int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32
     int rc = prof_begin(dev().prof[0], st, &e1);
     if (rc) return rc;
     if (D.gather) {
-        m.table = dev().d_edg_table; m.nwin = EDG_NWIN; m.nent = EDG_NENT; m.digw = DIGW; m.slot_ent = EDG_NWIN * EDG_NENT; m.uneven = 0;      // (digit rows keep their 13-word pitch)
+        m.table = dev().d_edg_table; m.nwin = EDG_NWIN; m.nent = EDG_NENT; m.digw = DIGW; m.slot_ent = EDG_NWIN * EDG_NENT; m.uneven = 0;
+        m.steps = D.steps; m.chunk_step0 = D.chunk_step0;
         const uint32_t tb = edg_msm_rows_per_block(), ngroups = (rows + tb - 1) / tb, nblocks = D.nchunks * ngroups;
         ZKP_TRACED("k_msm_gather<EdGather>", st, edg_launch_msm(m, ngroups, nblocks, st));
     } else {

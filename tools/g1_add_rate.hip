@@ -5,6 +5,7 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Ilibzkp_amd/csrc tools/g1_add_rate.hip -o build/tools/g1_add_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include "bn254_g.h"
 using namespace zkp;
@@ -73,11 +74,34 @@ template <int MAXW, bool NINE = false> void run(int waves, const uint32_t* d_pts
     printf("{\"form\": \"%s\", \"operands\": \"%s\", \"launch_bounds_waves\": %d, \"waves_per_simd\": %d, \"ms\": %.3f, \"g_adds_per_s\": %.2f, \"t_mad_per_s\": %.2f}\n", NINE ? "9x29" : "10x26", per_lane ? "per lane" : "same in every lane", MAXW, waves, best, adds / (best * 1e-3) / 1e9, adds * (NINE ? 1629 : 1810) / (best * 1e-3) / 1e12);
     (void)hipFree(d);
 }
-int main() {
+// `g1_add_rate sustain [seconds]`: the nine-limb loop at 3 waves per SIMD launched back to back for `seconds` (default 3): the rate a
+// launch reaches after the chip has been under this load for a while, against the best-of-four of a cold 5 ms launch that the table above
+// reports (a power-limited chip clocks down under sustained integer-multiply load: the ceiling a long-running prover sees is this one).
+static int sustain(double seconds, const uint32_t* d_pts) {
+    const int blocks = 256 * 3, iters = 400;
+    uint32_t* d; (void)hipMalloc(&d, (size_t)blocks * 256 * 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    const double adds = (double)blocks * 256 * iters;
+    double elapsed = 0; int n = 0; float first = 0, last = 0, lo = 1e30f, hi = 0;
+    while (elapsed < seconds * 1e3) {
+        (void)hipEventRecord(e0); k9<3><<<blocks, 256>>>(d_pts, d, iters, 1); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (n == 0) first = ms;
+        if (elapsed > seconds * 500.0) { if (ms < lo) lo = ms; if (ms > hi) hi = ms; }
+        last = ms; elapsed += ms; n++;
+    }
+    printf("{\"mode\": \"sustained\", \"form\": \"9x29\", \"waves_per_simd\": 3, \"launches\": %d, \"seconds\": %.2f, \"first_ms\": %.3f, \"last_ms\": %.3f, \"second_half_min_ms\": %.3f, \"second_half_max_ms\": %.3f, "
+           "\"g_adds_per_s_first\": %.2f, \"g_adds_per_s_last\": %.2f, \"g_adds_per_s_average\": %.2f}\n", n, elapsed / 1e3, first, last, lo, hi,
+           adds / (first * 1e-3) / 1e9, adds / (last * 1e-3) / 1e9, adds * n / (elapsed * 1e-3) / 1e9);
+    (void)hipFree(d);
+    return 0;
+}
+int main(int argc, char** argv) {
     static uint32_t h[40 * 256]; uint64_t s = 0x9E3779B97F4A7C15ull;
     for (int k = 0; k < 40; k++) h[k] = 0x1234567u * (k + 1) & 0x3ffffffu;      // < 2^26: carried in either form
     for (int k = 40; k < 40 * 256; k++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[k] = (uint32_t)s & 0x3ffffffu; }
     uint32_t* d_pts; (void)hipMalloc(&d_pts, sizeof h); (void)hipMemcpy(d_pts, h, sizeof h, hipMemcpyHostToDevice);
+    if (argc > 1 && argv[1][0] == 's') return sustain(argc > 2 ? atof(argv[2]) : 3.0, d_pts);
     for (int w : {1, 2, 3}) run<3>(w, d_pts);            // 168-VGPR budget, as the MSM kernel
     for (int w : {2, 4}) run<4>(w, d_pts);               // 128-VGPR budget
     for (int w : {1, 2}) run<2>(w, d_pts);               // 256-VGPR budget
