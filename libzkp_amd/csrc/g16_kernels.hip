@@ -64,14 +64,12 @@ __global__ void __launch_bounds__(TB) k_g16_zdigits(G16View V) {
     if (row < V.rows) step_g16_zdigits(V, blockIdx.y, row);
 }
 struct DevSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
-// one workgroup = one proof; the three polynomials (a, b, c evaluations -> h) live in LDS, word-major
-// 512 lanes: the 108 KB LDS image of a membership proof allows one workgroup per CU, so the workgroup itself has to bring the
-// waves (2 per SIMD) that hide the LDS latency of the butterfly stages
-static constexpr int QAP_TB = 512;
-__global__ void __launch_bounds__(QAP_TB) k_g16_qap(G16View V, G16Circuit C) {
+// one workgroup of m / 4 lanes = one proof; ONE polynomial's nine limb rows in LDS at a time (g16_steps.h: g16_qap_proof)
+static constexpr int QAP_TB_MAX = 256;
+__global__ void __launch_bounds__(QAP_TB_MAX) k_g16_qap(G16View V, G16Circuit C) {
     extern __shared__ uint32_t g16_lds[];
     G16Lds L; L.base = g16_lds; L.m = C.m;
-    g16_qap_proof(V, C, L, blockIdx.x, threadIdx.x, QAP_TB, DevSync());
+    g16_qap_proof(V, C, L, V.qap_evals + (size_t)blockIdx.x * 2 * 9 * C.m, blockIdx.x, threadIdx.x, blockDim.x, DevSync());
 }
 __global__ void __launch_bounds__(TW) k_g16_cparts(G16View V, const uint32_t* sum_g1, uint32_t* tmp_g1) {
     ZKP_RAISE_PRIO();
@@ -173,10 +171,10 @@ template __global__ void k_g16_build_table<fq2, 40>(const uint32_t*, uint32_t, u
 void g16_launch_witness(const G16View& V, hipStream_t st) { k_g16_witness<<<(V.rows + TW - 1) / TW, TW, 0, st>>>(V); }
 void g16_launch_zdigits(const G16View& V, hipStream_t st) { k_g16_zdigits<<<dim3((V.rows + TB - 1) / TB, V.nv), TB, 0, st>>>(V); }
 hipError_t g16_launch_qap(const G16View& V, const G16Circuit& C, hipStream_t st) {
-    const size_t lds = (size_t)3 * 9 * C.m * 4;         // three polynomials of nine-limb elements (54 KB at m = 512, 108 KB at m = 1024)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_g16_qap), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    k_g16_qap<<<V.rows, QAP_TB, lds, st>>>(V, C);
+    const size_t lds = (size_t)9 * C.m * 4;             // one polynomial of nine-limb elements (18 KB at m = 512, 36 KB at m = 1024)
+    const uint32_t tb = C.m / 4;
+    if (tb < 64 || tb > (uint32_t)QAP_TB_MAX || (tb & 63u)) return hipErrorInvalidValue;      // domains of 256 .. 1024 points
+    k_g16_qap<<<V.rows, tb, lds, st>>>(V, C);
     return hipSuccess;
 }
 void g16_launch_cparts(const G16View& V, const uint32_t* sum_g1, uint32_t* tmp_g1, hipStream_t st) {

@@ -110,6 +110,7 @@ struct G16View {
     uint32_t* z;                              // [nv][8][rows] full assignment (instance block first), Montgomery Fr
     uint32_t* sdig;                           // [nscalars][rx.digw][rows] packed digits: z_k (nv), h_i (m-1), r, s, -rs, one
     uint32_t* rs;                             // [2][8][rows] raw canonical r, s (for the variable-base part of C)
+    uint32_t* qap_evals;                      // [rows][2][9][m] the QAP step's coset evaluations of a and b while c is transformed
     // output
     uint8_t* out; uint64_t stride;            // envelope per row
 };
@@ -213,94 +214,135 @@ ZKP_HD inline uint32_t g16_bitrev(uint32_t x, uint32_t bits) {
     uint32_t r = 0; for (uint32_t i = 0; i < bits; i++) { r = (r << 1) | (x & 1u); x >>= 1; } return r;
 }
 
-// The QAP witness map of ONE proof on a word-major image x[poly][word][element] (LDS on the GPU).  `nthreads` lanes
-// cooperate; `sync` is the workgroup barrier.  Reference semantic: LibsnarkReduction::witness_map_from_matrices.
-// the three polynomials of a proof as nine-limb elements (bn254_fr9.h), word-major: 3 x 9 x m words
-// Element e of a word row sits at e ^ (31 if bit 5 of e is set): ds_read_b32 / ds_write_b32 bank a 32-lane half over 32 banks, and the
-// butterfly stages with half < 32 touch e = 2 half g + j (j < half) -- every second run of `half` consecutive words -- so that the lanes
-// of a half-wave with g's top bit set landed on the banks of those with it clear (2-way conflicts in five of the nine / ten stages of
-// each of the seven transforms; round 2 counted more conflict cycles than LDS-active cycles in this kernel).  Inverting the low five
-// address bits for those lanes sends them to exactly the banks the others leave free; for half >= 32 a half-wave reads 32 consecutive
-// words either way.
+// The QAP witness map of ONE proof (LibsnarkReduction::witness_map_from_matrices), `nthreads` lanes cooperating, `sync` the workgroup barrier.
+//
+// Round 4: ONE polynomial in LDS at a time, every pass of a transform does TWO butterfly stages, m / 4 lanes per proof.
+// Rounds 1-3 kept a, b and c in LDS together (54 / 108 KB: two / one workgroup per CU) and ran one radix-2 stage per barrier on 512 lanes
+// -- half of them idle at m = 512 --, 27 / 30 barriers per proof with two waves per SIMD to cover them: VALU active 28 %, time in the
+// barriers.  Now a workgroup of m / 4 lanes (128 / 256: two / four waves) holds nine limb rows of ONE polynomial (18 / 36 KB: eight / four
+// workgroups per CU, whose barriers interleave), a lane loads four elements, does the two butterflies of one stage and the two of the
+// next in registers and stores them: half the LDS traffic and half the barriers per stage.  a and b leave their coset evaluations in
+// a per-proof scratch block in HBM (2 x 36 m bytes, written and read once, coalesced) while c is transformed; the pointwise step reads
+// them back.  The arithmetic of every butterfly is unchanged (same operations in the same order on the same values: the bounds of
+// bn254_fr9.h / tests/test_fq_bounds.py hold as they are).
+//
+// Image: word row k (limb k of every element) is m words; element e of a row sits at sw(e) = e ^ (bit 5 of e ? 01010b : 0) ^ (bit 6 of e ?
+// 10101b : 0).  In a fused pass over stages (h, 2h) lane q touches e = (q / h) 4h + q % h + c h (c = 0..3); for h < 32 the 32 lanes of a
+// half-wave spread over address bits 5 and 6 while bits inside the low five go unused, and the two XOR masks fold those two bits back
+// into the unused bank bits for every h = 1, 2, 4, 8, 16 (the five 5 x 5 bit matrices are each of full rank), so every ds_read_b32 /
+// ds_write_b32 of a pass hits 32 different banks; within an aligned block of 32 elements sw() is a permutation, so the passes that walk
+// the image in element order (load, scale, pointwise, store) stay conflict-free as well.
 struct G16Lds {
     uint32_t* base; uint32_t m;
-    ZKP_HD static uint32_t sw(uint32_t e) { return e ^ ((0u - ((e >> 5) & 1u)) & 31u); }
-    ZKP_HD fr9 ld(uint32_t poly, uint32_t e) const { fr9 r; const uint32_t p = sw(e); ZKP_UNROLL for (int k = 0; k < 9; k++) r.v[k] = base[((size_t)poly * 9 + k) * m + p]; return r; }
-    ZKP_HD void st(uint32_t poly, uint32_t e, const fr9& v) const { const uint32_t p = sw(e); ZKP_UNROLL for (int k = 0; k < 9; k++) base[((size_t)poly * 9 + k) * m + p] = v.v[k]; }
+    ZKP_HD static uint32_t sw(uint32_t e) { return e ^ ((0u - ((e >> 5) & 1u)) & 10u) ^ ((0u - ((e >> 6) & 1u)) & 21u); }
+    ZKP_HD fr9 ld(uint32_t e) const { fr9 r; const uint32_t p = sw(e); ZKP_UNROLL for (int k = 0; k < 9; k++) r.v[k] = base[(size_t)k * m + p]; return r; }
+    ZKP_HD void st(uint32_t e, const fr9& v) const { const uint32_t p = sw(e); ZKP_UNROLL for (int k = 0; k < 9; k++) base[(size_t)k * m + p] = v.v[k]; }
 };
 ZKP_HD inline fr9 ld_fr9_c(const uint32_t* p, uint32_t idx) { fr9 r; ZKP_UNROLL for (int k = 0; k < 9; k++) r.v[k] = p[(size_t)idx * 9 + k]; return r; }
-// phase functions; each is called by every lane `tid` of the workgroup with a barrier between phases
-ZKP_HD inline void g16_qap_load(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t row, uint32_t tid, uint32_t nthreads) {
+// <row j of one R1CS matrix, z>.  Most coefficients of these circuits are 1 (linear combinations of MiMC rounds, the selector sums)
+// and many entries multiply the constant-one variable z_0: neither needs a field multiplication.
+ZKP_HD inline fr g16_row_dot_fast(const uint32_t* ptr, const uint32_t* col, const uint32_t* coef, uint32_t r, const uint32_t* z, uint32_t row, uint32_t rows) {
+    const fr one = fp_one<FrParams>();
+    fr acc = fp_zero<FrParams>();
+    for (uint32_t e = ptr[r]; e < ptr[r + 1]; e++) {
+        const fr cf = ld_fr_c(coef, e);
+        const uint32_t c = col[e];
+        bool is_one = true; ZKP_UNROLL for (int k = 0; k < 8; k++) is_one = is_one && cf.v[k] == one.v[k];
+        if (c == 0) acc = fp_add(acc, cf);                             // z_0 = 1 (the instance's leading one; Montgomery one times cf)
+        else if (is_one) acc = fp_add(acc, ld_fr(z, c, row, rows));
+        else acc = fp_add(acc, fp_mul(cf, ld_fr(z, c, row, rows)));
+    }
+    return acc;
+}
+// evaluations of polynomial `poly` (0 a, 1 b, 2 c) on the domain, natural order: element j = <row j, z>; a also carries the instance
+// rows (a[n_constraints + i] = z_i)
+ZKP_HD inline void g16_qap_load(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t poly, uint32_t row, uint32_t tid, uint32_t nthreads) {
     const uint32_t nc = C.n_rows;
-    // natural order: lane j evaluates constraint row j (consecutive lanes read consecutive CSR rows; the waves past the last row do
-    // nothing) and stores to position j.  The first transform is therefore decimation-in-frequency (natural in, bit-reversed out); a
-    // decimation-in-time first transform needed its input scattered to bit-reversed positions -- 32 lanes on two banks -- or, with the
-    // rows dealt in bit-reversed order instead, gave every wave a share of the padding rows (equality: 334 of 512 rows are real).
+    const uint32_t *ptr = poly == 0 ? C.a_ptr : poly == 1 ? C.b_ptr : C.c_ptr, *col = poly == 0 ? C.a_col : poly == 1 ? C.b_col : C.c_col,
+                   *coef = poly == 0 ? C.a_coef : poly == 1 ? C.b_coef : C.c_coef;
     for (uint32_t j = tid; j < C.m; j += nthreads) {
-        fr a = fp_zero<FrParams>(), b = a, c = a;
-        if (j < nc) {
-            a = g16_row_dot(C.a_ptr, C.a_col, C.a_coef, j, V.z, row, V.rows);
-            b = g16_row_dot(C.b_ptr, C.b_col, C.b_coef, j, V.z, row, V.rows);
-            c = g16_row_dot(C.c_ptr, C.c_col, C.c_coef, j, V.z, row, V.rows);
-        } else if (j < nc + V.n_inst) {
-            a = ld_fr(V.z, j - nc, row, V.rows);                    // a[n_constraints + i] = z_i (instance)
-        }
-        L.st(0, j, fr9_from_fr(a)); L.st(1, j, fr9_from_fr(b)); L.st(2, j, fr9_from_fr(c));      // < 1.4 r each
+        fr a = fp_zero<FrParams>();
+        if (j < nc) a = g16_row_dot_fast(ptr, col, coef, j, V.z, row, V.rows);
+        else if (poly == 0 && j < nc + V.n_inst) a = ld_fr(V.z, j - nc, row, V.rows);
+        L.st(j, fr9_from_fr(a));                                        // < 1.4 r
     }
 }
-// one DIT stage (len = 2*half) on `npoly` polynomials with twiddle table tw (stride m/len)
-ZKP_HD inline void g16_dit_stage(const G16Circuit& C, const G16Lds& L, const uint32_t* tw, uint32_t half, uint32_t npoly, uint32_t tid, uint32_t nthreads) {
+// the two butterflies (bounds: bn254_fr9.h)
+ZKP_HD inline void g16_bf_dif(fr9& u, fr9& v, const fr9& w) { const fr9 s = fr9_reduce_weak(fr9_add(u, v)); v = fr9_mul(fr9_sub_k<4>(u, v), w); u = s; }
+ZKP_HD inline void g16_bf_dit(fr9& u, fr9& v, const fr9& w) { const fr9 t = fr9_mul(v, w); v = fr9_sub_k<2>(u, t); u = fr9_add(u, t); }
+// one stage on its own (the odd stage of m = 512): m / 2 butterflies of half-length `half`
+template <bool DIF>
+ZKP_HD inline void g16_stage_single(const G16Circuit& C, const G16Lds& L, const uint32_t* tw, uint32_t half, uint32_t tid, uint32_t nthreads) {
     const uint32_t len = 2 * half, tstride = C.m / len;
     for (uint32_t k = tid; k < C.m / 2; k += nthreads) {
         const uint32_t grp = k / half, j = k % half, i0 = grp * len + j, i1 = i0 + half;
         const fr9 w = ld_fr9_c(tw, j * tstride);
-        for (uint32_t p = 0; p < npoly; p++) {                 // elements grow by <= 2 r per stage: < 22 r after ten (bn254_fr9.h)
-            const fr9 u = L.ld(p, i0), v = fr9_mul(L.ld(p, i1), w);
-            L.st(p, i0, fr9_add(u, v)); L.st(p, i1, fr9_sub_k<2>(u, v));
-        }
+        fr9 u = L.ld(i0), v = L.ld(i1);
+        if (DIF) g16_bf_dif(u, v, w); else g16_bf_dit(u, v, w);
+        L.st(i0, u); L.st(i1, v);
     }
 }
-ZKP_HD inline void g16_dif_stage(const G16Circuit& C, const G16Lds& L, const uint32_t* tw, uint32_t half, uint32_t npoly, uint32_t tid, uint32_t nthreads) {
-    const uint32_t len = 2 * half, tstride = C.m / len;
-    for (uint32_t k = tid; k < C.m / 2; k += nthreads) {
-        const uint32_t grp = k / half, j = k % half, i0 = grp * len + j, i1 = i0 + half;
-        const fr9 w = ld_fr9_c(tw, j * tstride);
-        for (uint32_t p = 0; p < npoly; p++) {                 // inputs < 2.3 r; the sum is brought back below 2.3 r, the product below 1.1 r
-            const fr9 u = L.ld(p, i0), v = L.ld(p, i1);
-            L.st(p, i0, fr9_reduce_weak(fr9_add(u, v))); L.st(p, i1, fr9_mul(fr9_sub_k<4>(u, v), w));
-        }
+// two stages in one pass: half-lengths (2h, h) for decimation in frequency, (h, 2h) for decimation in time; m / 4 tasks
+template <bool DIF>
+ZKP_HD inline void g16_stage_pair(const G16Circuit& C, const G16Lds& L, const uint32_t* tw, uint32_t h, uint32_t tid, uint32_t nthreads) {
+    const uint32_t s1 = C.m / (2 * h), s2 = C.m / (4 * h);           // twiddle strides of the stages with half-length h and 2h
+    for (uint32_t q = tid; q < C.m / 4; q += nthreads) {
+        const uint32_t grp = q / h, j = q % h, e0 = grp * 4 * h + j;
+        fr9 x0 = L.ld(e0), x1 = L.ld(e0 + h), x2 = L.ld(e0 + 2 * h), x3 = L.ld(e0 + 3 * h);
+        const fr9 wh = ld_fr9_c(tw, j * s1), wa = ld_fr9_c(tw, j * s2), wb = ld_fr9_c(tw, (j + h) * s2);
+        if (DIF) { g16_bf_dif(x0, x2, wa); g16_bf_dif(x1, x3, wb); g16_bf_dif(x0, x1, wh); g16_bf_dif(x2, x3, wh); }
+        else { g16_bf_dit(x0, x1, wh); g16_bf_dit(x2, x3, wh); g16_bf_dit(x0, x2, wa); g16_bf_dit(x1, x3, wb); }
+        L.st(e0, x0); L.st(e0 + h, x1); L.st(e0 + 2 * h, x2); L.st(e0 + 3 * h, x3);
     }
+}
+// decimation in frequency, natural in, bit-reversed out: half-lengths m/2 ... 1
+template <class Sync> ZKP_HD inline void g16_transform_dif(const G16Circuit& C, const G16Lds& L, const uint32_t* tw, uint32_t tid, uint32_t nthreads, Sync sync) {
+    uint32_t half = C.m / 2;
+    if (C.logm & 1u) { g16_stage_single<true>(C, L, tw, half, tid, nthreads); sync(); half >>= 1; }
+    for (; half >= 2; half >>= 2) { g16_stage_pair<true>(C, L, tw, half / 2, tid, nthreads); sync(); }
+}
+// decimation in time, bit-reversed in, natural out: half-lengths 1 ... m/2
+template <class Sync> ZKP_HD inline void g16_transform_dit(const G16Circuit& C, const G16Lds& L, const uint32_t* tw, uint32_t tid, uint32_t nthreads, Sync sync) {
+    uint32_t h = 1;
+    for (uint32_t i = 0; i < C.logm / 2; i++, h <<= 2) { g16_stage_pair<false>(C, L, tw, h, tid, nthreads); sync(); }
+    if (C.logm & 1u) { g16_stage_single<false>(C, L, tw, C.m / 2, tid, nthreads); sync(); }
 }
 // element at position p of a bit-reversed image has index bitrev(p): scale it by tab[bitrev(p)]
-ZKP_HD inline void g16_scale_bitrev(const G16Circuit& C, const G16Lds& L, const uint32_t* tab, uint32_t npoly, uint32_t tid, uint32_t nthreads) {
-    for (uint32_t p = tid; p < C.m; p += nthreads) {
-        const fr9 f = ld_fr9_c(tab, g16_bitrev(p, C.logm));
-        for (uint32_t q = 0; q < npoly; q++) L.st(q, p, fr9_mul(L.ld(q, p), f));
-    }
+ZKP_HD inline void g16_scale_bitrev(const G16Circuit& C, const G16Lds& L, const uint32_t* tab, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t p = tid; p < C.m; p += nthreads) L.st(p, fr9_mul(L.ld(p), ld_fr9_c(tab, g16_bitrev(p, C.logm))));
 }
-ZKP_HD inline void g16_pointwise(const G16Circuit& C, const G16Lds& L, uint32_t tid, uint32_t nthreads) {
+// the image as it lies in LDS <-> the proof's scratch block (coalesced both ways; the swizzle travels with the words)
+ZKP_HD inline void g16_spill(const G16Circuit& C, const G16Lds& L, uint32_t* dst, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t w = tid; w < 9 * C.m; w += nthreads) dst[w] = L.base[w];
+}
+ZKP_HD inline fr9 g16_ld_spilled(const uint32_t* src, uint32_t m, uint32_t e) { fr9 r; const uint32_t p = G16Lds::sw(e); ZKP_UNROLL for (int k = 0; k < 9; k++) r.v[k] = src[(size_t)k * m + p]; return r; }
+// (a b - c) / Z(g w^j) with a, b from the scratch block and c in LDS
+ZKP_HD inline void g16_pointwise(const G16Circuit& C, const G16Lds& L, const uint32_t* ea, const uint32_t* eb, uint32_t tid, uint32_t nthreads) {
     const fr9 zinv = ld_fr9_c(C.zinv, 0);
     for (uint32_t i = tid; i < C.m; i += nthreads)          // operands are outputs of ten decimation-in-time stages (< 22 r): a b < 3.9 r, c < 32 r
-        L.st(0, i, fr9_mul(fr9_sub_k<32>(fr9_mul(L.ld(0, i), L.ld(1, i)), L.ld(2, i)), zinv));
+        L.st(i, fr9_mul(fr9_sub_k<32>(fr9_mul(g16_ld_spilled(ea, C.m, i), g16_ld_spilled(eb, C.m, i)), L.ld(i)), zinv));
 }
 ZKP_HD inline void g16_store_h_bitrev(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t row, uint32_t tid, uint32_t nthreads) {
     for (uint32_t p = tid; p < C.m; p += nthreads) {
         const uint32_t i = g16_bitrev(p, C.logm);             // coefficient index of the element at position p
-        if (i + 1 < C.m) st_fr_digits(V.sdig, g16_sc_h(V) + i, row, V.rows, fr9_to_fr<FrParams>(fr9_mul(L.ld(0, p), ld_fr9_c(C.coset_inv, i))), V.rx);
+        if (i + 1 < C.m) st_fr_digits(V.sdig, g16_sc_h(V) + i, row, V.rows, fr9_to_fr<FrParams>(fr9_mul(L.ld(p), ld_fr9_c(C.coset_inv, i))), V.rx);
     }
 }
-// the whole witness map, written so that host emulation (nthreads = 1, sync = no-op) and the kernel share it.  Transform order:
-// DIF inverse (natural -> bit-reversed), coset scaling by index, DIT forward (bit-reversed -> natural), pointwise, DIF inverse,
-// coefficients read off by index: no pass of the LDS image is a bit-reversal scatter.
+// the whole witness map, written so that host emulation (nthreads = 1, sync = no-op) and the kernel share it.  Per polynomial: DIF
+// inverse (natural -> bit-reversed), coset scaling by index, DIT forward (bit-reversed -> natural); then pointwise, DIF inverse,
+// coefficients read off by index: no pass of the LDS image is a bit-reversal scatter.  scratch: 2 x 9 x m words of this proof.
 template <class Sync>
-ZKP_HD inline void g16_qap_proof(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t row, uint32_t tid, uint32_t nthreads, Sync sync) {
-    g16_qap_load(V, C, L, row, tid, nthreads); sync();
-    for (uint32_t half = C.m / 2; half >= 1; half >>= 1) { g16_dif_stage(C, L, C.tw_inv, half, 3, tid, nthreads); sync(); }   // iFFT (x m), bit-reversed out
-    g16_scale_bitrev(C, L, C.coset, 3, tid, nthreads); sync();                                                              // /m and coset shift g^i
-    for (uint32_t half = 1; half < C.m; half <<= 1) { g16_dit_stage(C, L, C.tw, half, 3, tid, nthreads); sync(); }            // coset FFT, natural out
-    g16_pointwise(C, L, tid, nthreads); sync();                                                                             // (a*b - c) / Z(g w^j)
-    for (uint32_t half = C.m / 2; half >= 1; half >>= 1) { g16_dif_stage(C, L, C.tw_inv, half, 1, tid, nthreads); sync(); }   // coset iFFT, bit-reversed out
-    g16_store_h_bitrev(V, C, L, row, tid, nthreads);                                                                        // /m, g^-i, digits
+ZKP_HD inline void g16_qap_proof(const G16View& V, const G16Circuit& C, const G16Lds& L, uint32_t* scratch, uint32_t row, uint32_t tid, uint32_t nthreads, Sync sync) {
+    for (uint32_t poly = 0; poly < 3; poly++) {
+        g16_qap_load(V, C, L, poly, row, tid, nthreads); sync();
+        g16_transform_dif(C, L, C.tw_inv, tid, nthreads, sync);                              // iFFT (x m), bit-reversed out
+        g16_scale_bitrev(C, L, C.coset, tid, nthreads); sync();                              // /m and coset shift g^i
+        g16_transform_dit(C, L, C.tw, tid, nthreads, sync);                                  // coset FFT, natural out
+        if (poly < 2) { g16_spill(C, L, scratch + (size_t)poly * 9 * C.m, tid, nthreads); sync(); }
+    }
+    g16_pointwise(C, L, scratch, scratch + (size_t)9 * C.m, tid, nthreads); sync();          // (a*b - c) / Z(g w^j)
+    g16_transform_dif(C, L, C.tw_inv, tid, nthreads, sync);                                  // coset iFFT, bit-reversed out
+    g16_store_h_bitrev(V, C, L, row, tid, nthreads);                                         // /m, g^-i, digits
 }
 
 // ---- final assembly.  thread = proof.  sums: [4 targets][words][rows] Jacobian sums A (G1), B1 (G1), Cp (G1), B2 (G2)

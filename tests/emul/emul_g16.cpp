@@ -32,9 +32,9 @@ int emul_g16_witness_qap(int kind, uint64_t value, const uint64_t* set_vals, uin
     C.b_ptr = T.ptr[1].data(); C.b_col = T.col[1].data(); C.b_coef = T.coef[1].data();
     C.c_ptr = T.ptr[2].data(); C.c_col = T.col[2].data(); C.c_coef = T.coef[2].data();
     C.tw = T.tw.data(); C.tw_inv = T.tw_inv.data(); C.coset = T.coset.data(); C.coset_inv = T.coset_inv.data(); C.zinv = T.zinv.data();
-    std::vector<uint32_t> lds((size_t)3 * 9 * T.m);
+    std::vector<uint32_t> lds((size_t)9 * T.m), scratch((size_t)2 * 9 * T.m);
     G16Lds L; L.base = lds.data(); L.m = T.m;
-    g16_qap_proof(V, C, L, 0, 0, 1, NoSync());
+    g16_qap_proof(V, C, L, scratch.data(), 0, 0, 1, NoSync());
     for (uint32_t k = 0; k < T.nv; k++) { fr x = ld_fr(z.data(), k, 0, 1); fp_to_raw(z_raw + 8 * k, x); }
     // digits -> canonical value (sum d_j 2^(WBITS j)), as 8 words
     auto undigit = [&](uint32_t idx, uint32_t* outw) {
