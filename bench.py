@@ -48,8 +48,9 @@ C5_BATCH = 16384
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md
 MAD_ISSUE_T = 35.157                     # T v_mad_u64_u32 lane-ops/s, isolated issue-rate measurement (profiles/r02_fe_microbench.json)
 MADS_PER_G1_MADD = 7 * 162 + 2 * 126 + 243      # g1_mmadd9 (XYZZ, nine 29-bit limbs): 7 products, 2 squarings, 1 fused double product (bn254_fq9.h)
-G1_BARE_LOOP_GADDS = 16.99               # G additions/s of the bare addition loop at 3 waves/SIMD, no loads (tools/g1_add_rate.hip, profiles/r02_g1_add_rate.jsonl)
+G1_BARE_LOOP_GADDS = 16.27               # G additions/s of the bare addition loop at 3 waves/SIMD, no loads, cold and sustained over 4 s alike (tools/g1_add_rate.hip, profiles/r04_g1_add_rate.jsonl; round 2 on another box: 16.99)
 MADS_PER_ED_MADD = 7 * 100               # mixed addition with an affine-Niels entry: 7 GF(2^255-19) products of 100 mads
+ED_KERNEL = "k_msm_gather<EdGather>"      # round 4: HBM-resident radix-2^16 generator tables (libzkp_amd/csrc/edg.h); rounds 1-3: k_msm_dma<EdMsm>
 ALGO_BYTES = {"range": 24 + 32 + 1478, "equality": 16 + 32 + 298, "membership16": 8 + 128 + 32 + 430}
 def _latest(name):
     """profiles/rNN_<name> of the latest round that has one"""
@@ -466,6 +467,27 @@ def main():
                                       "note": "BASELINE config 5: one seeded %d-op mixed batch, per-variant contiguous slices from zkp_hip_plan_shards, each rank proves its slice, "
                                               "blocking all_gather of the packed proofs inside the clock (max over ranks); not the contract's value" % nt}
 
+    # ------------------------------------------------------------------ the same contract steps with the opt-in key tables (child process)
+    # `value` above is measured at the library's DEFAULT key tables (radix 2^13, ~28 GB for the two circuits).  A deployment that gives the
+    # prover more HBM sets ZKP_HIP_G16_TABLE_BUDGET_MB: the same K steps under a 60 GB-per-key budget (radix 2^14 in its 18-window form, ~72 GB)
+    # are reported beside the contract's line, never as `value`.
+    if world == 1 and legs and not args.force_dist and not os.environ.get("ZKP_HIP_G16_TABLE_BUDGET_MB") and not os.environ.get("ZKP_HIP_G16_WBITS"):
+        L.zkp_hip_shutdown()
+        try:
+            env = dict(os.environ, ZKP_HIP_G16_TABLE_BUDGET_MB="60000")
+            pc = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-extra-legs"],
+                                capture_output=True, text=True, timeout=240, env=env)
+            lines = [x for x in pc.stdout.splitlines() if x.startswith("{")]
+            if pc.returncode == 0 and lines:
+                cj = json.loads(lines[-1])
+                extra["opt_in_key_tables"] = {"value": cj["value"], "unit": "proofs/s", "ms_per_step": cj["ms_per_step"], "g16_table_radix": cj.get("g16_table_radix"),
+                                              "g16_table_bytes": cj.get("g16_table_bytes"), "environment": "ZKP_HIP_G16_TABLE_BUDGET_MB=60000",
+                                              "note": "the contract's K steps again in a child process with the larger key tables opted in; not `value`"}
+            else:
+                extra["opt_in_key_tables"] = {"error": "child exited with %d: %s" % (pc.returncode, pc.stderr[-300:])}
+        except Exception as e:  # noqa: BLE001
+            extra["opt_in_key_tables"] = {"error": repr(e)[:300]}
+
     # ------------------------------------------------------------------ one process driving every visible GPU (the in-library multi-GPU path)
     # Runs in a CHILD process (started after this one has released the GPU: a new program, not an exec of this one): nothing that happens
     # in that leg -- it is the one path of this file that has never run on more than one physical GPU -- can cost the contract's line.
@@ -511,7 +533,7 @@ def main():
                           "fraction_of_bare_loop": adds_per_launch / (a_g1["avg_ms"] * 1e-3) / 1e9 / G1_BARE_LOOP_GADDS,
                           "hbm_frac": algo_launch / (a_g1["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "source": os.path.relpath(ALONE_CSV, ROOT),
                           "profiled_build": alone_build(), "this_build": csrc_sha16(), "stale": alone_build() != csrc_sha16()}
-        floor = sum(v["avg_ms"] * v["launches_per_step"] for k, v in alone.items() if k in ("k_msm_gather<G1Msm>", "k_msm_gather<G2Msm>", "k_msm_dma<EdMsm>", "k_g16_qap", "k_stark_prove"))
+        floor = sum(v["avg_ms"] * v["launches_per_step"] for k, v in alone.items() if k in ("k_msm_gather<G1Msm>", "k_msm_gather<G2Msm>", ED_KERNEL, "k_g16_qap", "k_stark_prove"))
         res = {
             "metric": "proofs/sec (whole node) + ms/proof p50, 4096-proof mixed batch (range / equality / membership / improvement) per MI355X",
             "value": total / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -547,13 +569,13 @@ def main():
                               "alone": alone_valu,
                               "peak_source": "profiles/r02_fe_microbench.json: isolated v_mad_u64_u32 issue rate (the multiply-adds of the field products only; "
                                              "carries, masks and loads share the same issue slots: a pure product chain reaches 75 % of it, the bare addition loop "
-                                             "(profiles/r02_g1_add_rate.jsonl) 75 %); launch durations are taken while the other variants' kernels share the GPU, "
+                                             "(profiles/r04_g1_add_rate.jsonl) 75 %); launch durations are taken while the other variants' kernels share the GPU, "
                                              "`alone` from the serialised counter pass"},
             "other_msm_kernels": {
                 "k_msm_gather<G2Msm>": {"avg_launch_ms": g2[0] / max(1, g2[1]), "launches": g2[1], "ms_per_step": g2[0] / max(1, args.steps),
                                         "point_additions_per_step": g2[2] / max(1, args.steps), "g_additions_per_s": g2[2] / (g2[0] * 1e-3) / 1e9 if g2[0] > 0 else None,
                                         "mads_per_point_addition": 4536},
-                "k_msm_dma<EdMsm>": {"avg_launch_ms": ed[0] / max(1, ed[1]), "launches": ed[1], "ms_per_step": ed[0] / max(1, args.steps),
+                ED_KERNEL: {"avg_launch_ms": ed[0] / max(1, ed[1]), "launches": ed[1], "ms_per_step": ed[0] / max(1, args.steps),
                                      "point_additions_per_step": ed[2] / max(1, args.steps), "g_additions_per_s": ed[2] / (ed[0] * 1e-3) / 1e9 if ed[0] > 0 else None,
                                      "valu_frac": (ed[2] * MADS_PER_ED_MADD / (ed[0] * 1e-3) / 1e12 / MAD_ISSUE_T) if ed[0] > 0 else None}},
         }

@@ -32,13 +32,17 @@ enum {
 
 /* Library-level return values: 0 = every item succeeded, 1 = at least one item has status != 0
  * (outputs of the other items are still valid), < 0 = the call itself failed (see zkp_hip_last_error). */
-#define ZKP_HIP_E_RUNTIME (-1)       /* HIP runtime error / no device / out of memory */
+/* No entry point lets a C++ exception out (the reference turns every failure into an Err: batch.rs:126-130): a failed host allocation or any
+ * other exception inside the library comes back as ZKP_HIP_E_RUNTIME with a message, and the library stays usable.  One call accepts at most
+ * 2^22 operations and 2^28 list values; beyond that ZKP_HIP_E_ARGUMENT, before anything is read or sized from the arguments. */
+#define ZKP_HIP_E_RUNTIME (-1)       /* HIP runtime error / no device / out of (host or device) memory / C++ exception */
 #define ZKP_HIP_E_UNSUPPORTED (-2)   /* e.g. n_bits other than 8, 16, 32, 64 */
 #define ZKP_HIP_E_ARGUMENT (-3)
 
 /* One-time setup on HIP device `device`: derives the 130 Bulletproofs generators (PedersenGens::default,
  * BulletproofGens::new party 0; replaces bp_gens_pair_bits, bulletproofs.rs:61-80), builds the
- * fixed-base window tables and uploads them.  Idempotent.  Called implicitly (device 0) by the prove calls.
+ * fixed-base window tables on the device (radix 2^16: 8.7 GB of HBM per GPU, self-checked slot against slot; plus 208 MB of radix-1024
+ * tables for the verifier).  Idempotent.  Called implicitly (device 0) by the prove calls.
  * Every device initialised this way becomes one SHARD of the library (numbered in registration order). */
 int zkp_hip_init(int device);
 /* Multi-GPU (replaces the rayon fan-out of batch.rs:123-131 at node scale): registers `count` shards, shard k on

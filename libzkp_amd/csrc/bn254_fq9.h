@@ -153,6 +153,15 @@ template <int K> ZKP_HD inline fq9 fq9_sub2_k(const fq9& a, const fq9& b, const 
     return r;
 }
 ZKP_HD inline fq9 fq9_sub2_k4(const fq9& a, const fq9& b, const fq9& c2) { return fq9_sub2_k<4>(a, b, c2); }
+// ---- loose differences (round 4).  A column of 9 + 9 products of 29-bit limbs leaves under two bits of the accumulator, so this form has no
+// limb-wise lazy sums in general -- but ONE operand of each product of a fused double product may be loose: a - b + K p taken limb by limb
+// from a "fat" form of K p (the same integer with every limb below the top in [2^29 - 1, 2^30), so that no limb difference is negative), no
+// carry pass.  Limbs of the result: < 2^29 + 2^30 for a - b + K p, < 2^30 for K p - b.  fq9_mul_add2(carried, loose, loose', carried)
+// then sums 9 x 2^59.6 + 9 x 2^59 + 9 x 2^58 (reduction) < 2^63.8 per column (tests/test_fq_bounds.py).  Measured on the bare addition
+// loop (tools/g1_add_rate.hip loose, profiles/r04_g1_add_rate.jsonl): 16.2 -> 16.8 G additions/s with the two carry passes of Y3 folded away.
+template <int K> ZKP_HD constexpr uint32_t fq9_fat(int i) { return i == 0 ? fq9_kp<K>(0) + (1u << 29) : i < 8 ? fq9_kp<K>(i) + (1u << 29) - 1u : fq9_kp<K>(8) - 1u; }
+template <int K> ZKP_HD inline fq9 fq9_sub_loose(const fq9& a, const fq9& b) { fq9 r; ZKP_UNROLL for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + fq9_fat<K>(i) - b.v[i]; return r; }
+template <int K> ZKP_HD inline fq9 fq9_neg_loose(const fq9& b) { fq9 r; ZKP_UNROLL for (int i = 0; i < 9; i++) r.v[i] = fq9_fat<K>(i) - b.v[i]; return r; }
 // K p - a (a < K p)
 template <int K> ZKP_HD inline fq9 fq9_neg_k(const fq9& a) { return fq9_sub_k<K>(fq9_zero(), a); }
 // a + b, carried (values must leave the sum below 2^261)

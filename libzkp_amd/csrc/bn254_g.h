@@ -140,7 +140,7 @@ ZKP_HD inline g1_xyzz9 g1_mmadd9(const g1_xyzz9& p, const g1_aff9& q) {
     const fq9 RR = fq9_sq(Rv);
     g1_xyzz9 r;
     r.X = fq9_sub2_k4(RR, PPP, Q);                                       // R^2 - PPP - 2 Q + 4p
-    r.Y = fq9_mul_add2(Rv, fq9_sub_k<8>(Q, r.X), fq9_neg_k<4>(p.Y), PPP);      // R (Q - X3) + (4p - Y1) PPP, one reduction
+    r.Y = fq9_mul_add2(Rv, fq9_sub_loose<8>(Q, r.X), fq9_neg_loose<4>(p.Y), PPP);      // R (Q - X3 + 8p) + (4p - Y1) PPP, one reduction; the two differences stay loose (bn254_fq9.h)
     r.ZZ = fq9_mul(p.ZZ, PP);
     r.ZZZ = fq9_mul(p.ZZZ, PPP);
     return r;

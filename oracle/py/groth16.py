@@ -364,6 +364,41 @@ def verify(pk, public_inputs, proof):
     return bn.pairing_product_is_one([(A, B), (neg(pk.alpha_g1), pk.beta_g2), (neg(acc), pk.gamma_g2), (neg(C), pk.delta_g2)])
 
 
+class VerifyingKey:
+    """The verifying key that leads an ark-serialize uncompressed ProvingKey<Bn254> file (snark.rs:31-38: `{prefix}_pk.bin`):
+    alpha_g1 | beta_g2 | gamma_g2 | delta_g2 | u64 n | gamma_abc_g1[n].  Enough for verify() above (it reads exactly these fields)."""
+
+
+def vk_from_pk_bytes(blob):
+    vk = VerifyingKey()
+    ok, vk.alpha_g1 = bn.de_g1(blob[0:64])
+    ok2, vk.beta_g2 = bn.de_g2(blob[64:192])
+    ok3, vk.gamma_g2 = bn.de_g2(blob[192:320])
+    ok4, vk.delta_g2 = bn.de_g2(blob[320:448])
+    n = int.from_bytes(blob[448:456], "little")
+    if not (ok and ok2 and ok3 and ok4) or n > 1 << 16 or len(blob) < 456 + 64 * n:
+        raise ValueError("malformed key file")
+    vk.gamma_abc_g1 = []
+    for i in range(n):
+        ok, pt = bn.de_g1(blob[456 + 64 * i:520 + 64 * i])
+        if not ok:
+            raise ValueError("malformed key file")
+        vk.gamma_abc_g1.append(pt)
+    return vk
+
+
+def verify_equality_envelope_under(vk, proof_env):
+    """verify_equality_with_commitment's framing checks with the envelope's own commitment, under an explicit key."""
+    if len(proof_env) != 298 or proof_env[:2] != bytes([2, 2]):
+        return False
+    if int.from_bytes(proof_env[2:6], "little") != 256 or int.from_bytes(proof_env[6:10], "little") != 32:
+        return False
+    c = int.from_bytes(proof_env[266:298], "little")
+    if c >= R:
+        return False
+    return verify(vk, [c], proof_env[10:266])
+
+
 # ---------------------------------------------------------------- libzkp framing
 _KEYS = {}
 

@@ -14,12 +14,19 @@
 //!      `zkp_hip_groth16_load_key`, and proofs made with it on the GPU verify under the reference -- i.e. the R1CS matrices, variable
 //!      order and QAP reduction are ark-groth16's;
 //!   4. `prove_improvement` -- the one deterministic scheme -- is BYTE-IDENTICAL (stark.rs:151-186);
-//!   5. `commit_value_snark` (MiMC constants, snark.rs:186-221) is byte-identical.
+//!   5. `commit_value_snark` (MiMC constants, snark.rs:186-221) is byte-identical;
+//!   6. (round 4) the form of the device tables is invisible in the bytes: the reference's key loaded under every radix policy this
+//!      library has (default 2^13, the 2^14 opt-in in its even and its 18-window form, a forced small radix) gives the SAME envelope for
+//!      the same seed, and the reference accepts it -- the radix-2^16 generator tables of the range prover and the scratch-free STARK
+//!      kernel are covered by claims 1 and 4, whose envelopes they now produce;
+//!   7. (round 4) Groth16 envelopes with a point at infinity -- crafted from a reference envelope, the encodings ark-serialize accepts --
+//!      get the SAME verdict from the reference and from the HIP verifiers (they leave the Fq2 machine for the lane-per-chain kernels).
 //! and what it writes into $LIBZKP_HIP_VECTORS (consumed by tests/test_reference_vectors.py, which skips while the directory is empty):
 //!   reference_envelopes.json   envelopes made by the reference            -> our verifiers must keep accepting them
 //!   hip_envelopes.json         inputs + seeds + envelopes made on the GPU that the reference accepted -> our prover must keep producing exactly them
 //!   improvement_vectors.json   (old, new, envelope) from the reference    -> our prover must produce exactly them
 //!   snark_commitments.json     (value, commitment) from the reference
+//!   special_envelopes.json     crafted envelopes (points at infinity) with the reference's verdict -> our verifiers must give the same
 //!   equality_mimc_{pk,vk}.bin, membership_mimc_{pk,vk}.bin               the reference's own trusted setup
 use libzkp::backend::hip_ffi as ffi;
 use libzkp::proof::{consistency_proof, equality_proof, improvement_proof, range_proof, set_membership, threshold_proof};
@@ -173,6 +180,50 @@ fn hip_backend_and_reference_accept_each_other() {
     cms.truncate(cms.len() - 2);
     cms.push_str("\n]\n");
     std::fs::write(dir.join("snark_commitments.json"), cms).unwrap();
+
+    // ---- 6. table forms: same key, same seed, same bytes whatever the radix policy of the device tables
+    {
+        let sd = seed(777);
+        let eq_default = hip_prove(op(ffi::OP_EQUALITY, 0, 42, 42, 0), &[], &sd);
+        let mem_default = hip_prove(op(ffi::OP_MEMBERSHIP, 3, 2, 0, 0), &[1, 2, 3], &sd);
+        for (name, value) in [("ZKP_HIP_G16_TABLE_BUDGET_MB", "60000"), ("ZKP_HIP_G16_UNEVEN", "0"), ("ZKP_HIP_G16_WBITS", "11")] {
+            std::env::set_var(name, value);
+            if name == "ZKP_HIP_G16_UNEVEN" { std::env::set_var("ZKP_HIP_G16_TABLE_BUDGET_MB", "60000"); }
+            for (kind, file) in [(0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")] {
+                let pk = std::fs::read(dir.join(file)).unwrap();
+                assert_eq!(unsafe { ffi::zkp_hip_groth16_load_key(kind, pk.as_ptr(), pk.len() as u64) }, 0, "{}", ffi::last_error());
+            }
+            let (mut wb, mut un, mut bytes) = (0u32, 0u32, 0u64);
+            assert_eq!(unsafe { ffi::zkp_hip_groth16_key_info(0, &mut wb, &mut un, &mut bytes) }, 0);
+            eprintln!("table form under {}={}: radix 2^{} uneven {} ({} MB)", name, value, wb, un, bytes >> 20);
+            assert_eq!(hip_prove(op(ffi::OP_EQUALITY, 0, 42, 42, 0), &[], &sd), eq_default, "equality envelope depends on the table form ({}={})", name, value);
+            assert_eq!(hip_prove(op(ffi::OP_MEMBERSHIP, 3, 2, 0, 0), &[1, 2, 3], &sd), mem_default, "membership envelope depends on the table form");
+            std::env::remove_var("ZKP_HIP_G16_TABLE_BUDGET_MB"); std::env::remove_var("ZKP_HIP_G16_UNEVEN"); std::env::remove_var("ZKP_HIP_G16_WBITS");
+        }
+        for (kind, file) in [(0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")] {          // back to the default policy
+            let pk = std::fs::read(dir.join(file)).unwrap();
+            assert_eq!(unsafe { ffi::zkp_hip_groth16_load_key(kind, pk.as_ptr(), pk.len() as u64) }, 0);
+        }
+        assert!(equality_proof::verify_equality(eq_default, 42, 42));
+    }
+
+    // ---- 7. crafted points at infinity: the verdicts must agree, whatever they are (ark-serialize: flag 0x40 in the last byte, all else zero)
+    {
+        let mut specials = String::from("[\n");
+        let base = ref_eq.clone();                                  // [10-byte header][A 64][B 128][C 64][commitment 32]
+        for (what, at, len) in [("A", 10usize, 64usize), ("B", 74, 128), ("C", 202, 64)] {
+            let mut e = base.clone();
+            for b in &mut e[at..at + len] { *b = 0; }
+            e[at + len - 1] = 0x40;
+            let want = equality_proof::verify_equality(e.clone(), 42, 42);
+            assert_eq!(unsafe { ffi::zkp_hip_verify_equality_batch(1, e.as_ptr(), e.len() as u64, [e.len() as u32].as_ptr(), ok.as_mut_ptr()) }, 0);
+            assert_eq!(ok[0] == 1, want, "equality envelope with {} at infinity: reference says {}, HIP says {}", what, want, ok[0]);
+            writeln!(specials, "  {{\"scheme\": \"equality\", \"what\": \"{} at infinity\", \"verify_args\": {{\"value\": 42}}, \"envelope\": \"{}\", \"reference_verdict\": {}}},", what, hex(&e), want).unwrap();
+        }
+        specials.truncate(specials.len() - 2);
+        specials.push_str("\n]\n");
+        std::fs::write(dir.join("special_envelopes.json"), specials).unwrap();
+    }
 
     // negative cases of tests/integration.rs:72-91 against HIP envelopes
     let mut bad = hip_prove(op(ffi::OP_RANGE, 0, 7, 0, 10), &[], &seed(99));

@@ -237,6 +237,7 @@ def header_constants9():
 
 
 def test_nine_limb_constants_and_column_sums():
+    import os
     c = header_constants9()
     val = lambda l: sum(x << (29 * i) for i, x in enumerate(l))  # noqa: E731
     assert val(c["fq9_pl"]) == P and val(c["fq9_k2"]) == 2 * P and val(c["fq9_k4"]) == 4 * P and val(c["fq9_k8"]) == 8 * P
@@ -251,6 +252,20 @@ def test_nine_limb_constants_and_column_sums():
     # fq9_mul_add2: 18 operand products + 9 reduction products
     col2 = 18 * m29 * m29 + 9 * m29 * max(c["fq9_pl"])
     assert col2 + (col2 >> 29) < 1 << 64
+    # round 4: the fused double product of Y3 takes two LOOSE operands, limb-wise differences against fat forms of 8p / 4p (fq9_sub_loose,
+    # fq9_neg_loose): the fat forms are the same integers, no limb difference goes negative, and the widest column still fits 64 bits
+    src = open(os.path.join(os.path.dirname(__file__), "..", "libzkp_amd", "csrc", "bn254_fq9.h")).read()
+    assert "i == 0 ? fq9_kp<K>(0) + (1u << 29) : i < 8 ? fq9_kp<K>(i) + (1u << 29) - 1u : fq9_kp<K>(8) - 1u" in src
+    for name, k in (("fq9_k8", 8), ("fq9_k4", 4)):
+        fat = [c[name][0] + (1 << 29)] + [c[name][i] + (1 << 29) - 1 for i in range(1, 8)] + [c[name][8] - 1]
+        assert val(fat) == k * P
+        assert all(f >= m29 for f in fat[:8]) and all(f < 1 << 30 for f in fat) and fat[8] > 0       # a_i + fat_i - b_i >= 0 for carried a, b (limbs <= 2^29 - 1)
+    loose8, loose4 = m29 + (1 << 30) - 1, (1 << 30) - 1                                               # limbs of Q - X3 + 8p and of 4p - Y1
+    col_l = 9 * m29 * loose8 + 9 * loose4 * m29 + 9 * m29 * max(c["fq9_pl"])
+    assert col_l + (col_l >> 29) < 1 << 64
+    # the top limb of a loose difference stays positive: the VALUE Q - X3 + 8p is at least 8p - X3 > 2.8 p (X3 < 5.2 p, test below), and the
+    # lower limbs hold at most 2 units more than their carried share each
+    assert (28 * P // 10) >> (29 * 8) > 4
     # fq9_sub_k / fq9_sub2_k4: limb expressions fit int32 with the running carry
     assert m29 + max(c["fq9_k8"]) + 1 < 1 << 31 and -(m29 + 2 * m29 + 4) > -(1 << 31)
 

@@ -7,6 +7,7 @@ development image), so every test below is skipped until vectors appear; nothing
                              exactly those bytes (so the reference's acceptance carries over to today's code)
   improvement_vectors.json   the reference's deterministic STARK envelopes -> byte parity of both provers
   snark_commitments.json     commit_value_snark                            -> MiMC parity
+  special_envelopes.json     crafted Groth16 envelopes (a point at infinity) with the reference's verdict -> oracle and HIP verifiers must agree with it
   *_mimc_pk.bin              the reference's own Groth16 setup (loaded before the equality / membership cases)
 """
 import ctypes
@@ -103,6 +104,18 @@ def test_oracle_verifier_accepts_the_reference_range_envelopes(oracle_c):
             assert oracle_c.zkp_oracle_verify_consistency(e, len(e)) == 1
 
 
+def test_oracle_verdicts_on_crafted_envelopes_equal_the_reference():
+    from oracle.py import groth16 as g
+    keys = dict(_ref_keys())
+    if 0 not in keys:
+        pytest.skip("no equality key among the vectors")
+    vk = g.vk_from_pk_bytes(keys[0])
+    for rec in _load("special_envelopes.json"):
+        if rec["scheme"] != "equality":
+            continue
+        assert g.verify_equality_envelope_under(vk, bytes.fromhex(rec["envelope"])) == bool(rec["reference_verdict"]), rec["what"]
+
+
 # ------------------------------------------------------------------------------------------------ GPU tier: the HIP backend against the reference
 @pytest.fixture()
 def hip_with_reference_keys():
@@ -156,3 +169,35 @@ def test_hip_verifiers_accept_the_reference_envelopes(hip_with_reference_keys):
             o = u(a["old"])
             rc = L.zkp_hip_verify_improvement_batch(1, P(e), len(e), P(ln), P(o), P(ok))
         assert rc == 0 and ok[0] == 1, s
+
+
+@pytest.mark.gpu
+def test_hip_verdicts_on_crafted_envelopes_equal_the_reference(hip_with_reference_keys):
+    """Envelopes with a point at infinity leave the Fq2 machine for the lane-per-chain kernels: same verdict as the reference either way."""
+    from util import P
+    L = hip_with_reference_keys
+    for rec in _load("special_envelopes.json"):
+        e = np.frombuffer(bytes.fromhex(rec["envelope"]), dtype=np.uint8).copy()
+        ln = np.array([len(e)], dtype=np.uint32); ok = np.zeros(1, dtype=np.uint8)
+        fn = L.zkp_hip_verify_equality_batch if rec["scheme"] == "equality" else L.zkp_hip_verify_membership_batch
+        assert fn(1, P(e), len(e), P(ln), P(ok)) == 0 and bool(ok[0]) == bool(rec["reference_verdict"]), rec["what"]
+
+
+@pytest.mark.gpu
+def test_hip_envelopes_do_not_depend_on_the_table_form(hip_with_reference_keys):
+    """The reference's key under every radix policy of the device tables gives the recorded envelope for the recorded seed."""
+    from libzkp_amd import _native
+    L = hip_with_reference_keys
+    recs = [r for r in _load("hip_envelopes.json") if r["scheme"] in ("equality", "membership")]
+    try:
+        for env in ({"ZKP_HIP_G16_TABLE_BUDGET_MB": "60000"}, {"ZKP_HIP_G16_TABLE_BUDGET_MB": "60000", "ZKP_HIP_G16_UNEVEN": "0"}, {"ZKP_HIP_G16_WBITS": "11"}):
+            os.environ.update(env)
+            for kind, blob in _ref_keys():
+                assert L.zkp_hip_groth16_load_key(kind, blob, len(blob)) == 0, _native.last_error()
+            for rec in recs:
+                assert _prove_one(L.zkp_hip_process_batch, rec).hex() == rec["envelope"], (rec["scheme"], env)
+            for k in env:
+                del os.environ[k]
+    finally:
+        for k in ("ZKP_HIP_G16_TABLE_BUDGET_MB", "ZKP_HIP_G16_UNEVEN", "ZKP_HIP_G16_WBITS"):
+            os.environ.pop(k, None)

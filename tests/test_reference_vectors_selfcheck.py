@@ -56,6 +56,17 @@ def _stand_in_vectors(orc, d):
             dict(scheme="membership", verify_args=dict(set=[1, 2, 3]), envelope=hips[4]["envelope"]),
             dict(scheme="improvement", verify_args=dict(old=1), envelope=prove(5, 0, 1, 5, 0, None, sd(0)))]
     json.dump(refs, open(os.path.join(d, "reference_envelopes.json"), "w"))
+    # crafted points at infinity in the equality envelope (A, B, C in turn), verdicts by the oracle's pairing verifier
+    from oracle.py import groth16 as g
+    vk = g.vk_from_pk_bytes(open(os.path.join(GOLD, "equality_mimc_pk.bin"), "rb").read())
+    specials = []
+    base = bytes.fromhex(hips[3]["envelope"])
+    assert g.verify_equality_envelope_under(vk, base)
+    for what, at, ln in (("A", 10, 64), ("B", 74, 128), ("C", 202, 64)):
+        e = bytearray(base); e[at:at + ln] = bytes(ln); e[at + ln - 1] = 0x40
+        specials.append(dict(scheme="equality", what=what + " at infinity", verify_args=dict(value=42), envelope=bytes(e).hex(),
+                             reference_verdict=bool(g.verify_equality_envelope_under(vk, bytes(e)))))
+    json.dump(specials, open(os.path.join(d, "special_envelopes.json"), "w"))
 
 
 def _run_consumer(d, marker):
@@ -68,11 +79,11 @@ def _run_consumer(d, marker):
 def test_consumer_runs_every_cpu_case_on_stand_in_vectors(oracle_c, tmp_path):
     _stand_in_vectors(oracle_c, str(tmp_path))
     rc, tail = _run_consumer(str(tmp_path), "not gpu")
-    assert rc == 0 and "3 passed" in tail and "skipped" not in tail, tail
+    assert rc == 0 and "4 passed" in tail and "skipped" not in tail, tail
 
 
 @pytest.mark.gpu
 def test_consumer_runs_every_gpu_case_on_stand_in_vectors(oracle_c, tmp_path):
     _stand_in_vectors(oracle_c, str(tmp_path))
     rc, tail = _run_consumer(str(tmp_path), "gpu")
-    assert rc == 0 and "2 passed" in tail and "skipped" not in tail, tail
+    assert rc == 0 and "4 passed" in tail and "skipped" not in tail, tail

@@ -27,6 +27,83 @@ __global__ void __launch_bounds__(256, MAXW) k9(const uint32_t* pts, uint32_t* o
     uint32_t s = 0; for (int k = 0; k < 9; k++) s ^= acc.X.v[k] ^ acc.Y.v[k] ^ acc.ZZ.v[k] ^ acc.ZZZ.v[k];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+// ---- round 4, an alternative column form: two of the five carry passes of the addition folded away.  The nine-limb
+// form has no room for limb-wise lazy sums in general (a column of 9 + 9 products of 29-bit limbs leaves under two bits of the 64-bit
+// accumulator), but ONE operand of a product may be loose: Y3 = R (Q - X3) + (4p - Y1) PPP takes (Q - X3 + 8p) and (4p - Y1) limb by limb
+// from "fat" forms of 8p / 4p (every limb below the top in [2^29 - 1, 2^30), same integer), no carry pass: limbs < 2^30.6, column sums
+// 9 x 2^59.6 + 9 x 2^59 + 9 x 2^58 < 2^63.7.  Saves 2 x 18 of the ~2 070 issue units of an addition.
+// (adopted: this is g1_mmadd9 of bn254_g.h since round 4; the carried form is kept below for the comparison)
+__device__ __forceinline__ g1_xyzz9 g1_mmadd9_loose(const g1_xyzz9& p, const g1_aff9& q) {
+    const fq9 U2 = fq9_mul(q.x, p.ZZ), S2 = fq9_mul(q.y, p.ZZZ);
+    const fq9 P = fq9_sub_k<8>(U2, p.X), Rv = fq9_sub_k<4>(S2, p.Y);
+    const fq9 PP = fq9_sq(P);
+    const fq9 PPP = fq9_mul(P, PP), Q = fq9_mul(p.X, PP);
+    const fq9 RR = fq9_sq(Rv);
+    g1_xyzz9 r;
+    r.X = fq9_sub2_k4(RR, PPP, Q);
+    r.Y = fq9_mul_add2(Rv, fq9_sub_loose<8>(Q, r.X), fq9_neg_loose<4>(p.Y), PPP);
+    r.ZZ = fq9_mul(p.ZZ, PP);
+    r.ZZZ = fq9_mul(p.ZZZ, PPP);
+    return r;
+}
+__device__ __forceinline__ g1_xyzz9 g1_mmadd9_carried(const g1_xyzz9& p, const g1_aff9& q) {       // rounds 2-3: every difference carried
+    const fq9 U2 = fq9_mul(q.x, p.ZZ), S2 = fq9_mul(q.y, p.ZZZ);
+    const fq9 P = fq9_sub_k<8>(U2, p.X), Rv = fq9_sub_k<4>(S2, p.Y);
+    const fq9 PP = fq9_sq(P);
+    const fq9 PPP = fq9_mul(P, PP), Q = fq9_mul(p.X, PP);
+    const fq9 RR = fq9_sq(Rv);
+    g1_xyzz9 r;
+    r.X = fq9_sub2_k4(RR, PPP, Q);
+    r.Y = fq9_mul_add2(Rv, fq9_sub_k<8>(Q, r.X), fq9_neg_k<4>(p.Y), PPP);
+    r.ZZ = fq9_mul(p.ZZ, PP);
+    r.ZZZ = fq9_mul(p.ZZZ, PPP);
+    return r;
+}
+template <int MAXW>
+__global__ void __launch_bounds__(256, MAXW) k9c(const uint32_t* pts, uint32_t* out, int iters, int per_lane) {
+    g1_aff9 q[2];
+    const uint32_t* src = pts + (per_lane ? 40u * threadIdx.x : 0u);
+    for (int j = 0; j < 2; j++) for (int k = 0; k < 9; k++) { q[j].x.v[k] = src[j * 20 + k]; q[j].y.v[k] = src[j * 20 + 10 + k]; }
+    g1_xyzz9 acc; acc.X = q[0].x; acc.Y = q[0].y; acc.ZZ = q[1].x; acc.ZZZ = q[1].y;
+    acc.X.v[0] ^= threadIdx.x & 1u;
+    for (int it = 0; it < iters; it++) {
+        g1_aff9 e = q[it & 1];
+        e.y = fq9_select((it >> 1) & 1, fq9_neg_k<4>(e.y), e.y);
+        acc = g1_mmadd9_carried(acc, e);
+    }
+    uint32_t s = 0; for (int k = 0; k < 9; k++) s ^= acc.X.v[k] ^ acc.Y.v[k] ^ acc.ZZ.v[k] ^ acc.ZZZ.v[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int MAXW>
+__global__ void __launch_bounds__(256, MAXW) k9l(const uint32_t* pts, uint32_t* out, int iters, int per_lane) {
+    g1_aff9 q[2];
+    const uint32_t* src = pts + (per_lane ? 40u * threadIdx.x : 0u);
+    for (int j = 0; j < 2; j++) for (int k = 0; k < 9; k++) { q[j].x.v[k] = src[j * 20 + k]; q[j].y.v[k] = src[j * 20 + 10 + k]; }
+    g1_xyzz9 acc; acc.X = q[0].x; acc.Y = q[0].y; acc.ZZ = q[1].x; acc.ZZZ = q[1].y;
+    acc.X.v[0] ^= threadIdx.x & 1u;
+    for (int it = 0; it < iters; it++) {
+        g1_aff9 e = q[it & 1];
+        e.y = fq9_select((it >> 1) & 1, fq9_neg_k<4>(e.y), e.y);
+        acc = g1_mmadd9_loose(acc, e);
+    }
+    uint32_t s = 0; for (int k = 0; k < 9; k++) s ^= acc.X.v[k] ^ acc.Y.v[k] ^ acc.ZZ.v[k] ^ acc.ZZZ.v[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+static void run_loose(int waves, const uint32_t* d_pts) {
+    const int blocks = 256 * waves, iters = 400;
+    uint32_t* d; (void)hipMalloc(&d, (size_t)blocks * 256 * 4);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best[2] = {1e30f, 1e30f};
+    for (int r = 0; r < 6; r++) for (int v = 0; v < 2; v++) {                     // alternately, so that both forms see the same clocks
+        (void)hipEventRecord(e0);
+        if (v == 0) k9c<3><<<blocks, 256>>>(d_pts, d, iters, 1); else k9l<3><<<blocks, 256>>>(d_pts, d, iters, 1);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best[v]) best[v] = ms;
+    }
+    const double adds = (double)blocks * 256 * iters;
+    printf("{\"experiment\": \"carry passes of Q - X3 and 4p - Y1 folded into the fused double product (loose operands)\", \"waves_per_simd\": %d, \"carried_ms\": %.3f, \"loose_ms\": %.3f, "
+           "\"carried_g_adds_per_s\": %.2f, \"loose_g_adds_per_s\": %.2f}\n", waves, best[0], best[1], adds / (best[0] * 1e-3) / 1e9, adds / (best[1] * 1e-3) / 1e9);
+    (void)hipFree(d);
+}
 // the G2 loop body (g2_mmadd9: XYZZ over Fq2 on nine limbs), 2 waves per SIMD as k_msm_gather<G2Msm>
 __global__ void __launch_bounds__(256, 2) k2(const uint32_t* pts, uint32_t* out, int iters) {
     g2_aff9 q[2];
@@ -102,6 +179,7 @@ int main(int argc, char** argv) {
     for (int k = 40; k < 40 * 256; k++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h[k] = (uint32_t)s & 0x3ffffffu; }
     uint32_t* d_pts; (void)hipMalloc(&d_pts, sizeof h); (void)hipMemcpy(d_pts, h, sizeof h, hipMemcpyHostToDevice);
     if (argc > 1 && argv[1][0] == 's') return sustain(argc > 2 ? atof(argv[2]) : 3.0, d_pts);
+    if (argc > 1 && argv[1][0] == 'l') { run_loose(2, d_pts); run_loose(3, d_pts); return 0; }
     for (int w : {1, 2, 3}) run<3>(w, d_pts);            // 168-VGPR budget, as the MSM kernel
     for (int w : {2, 4}) run<4>(w, d_pts);               // 128-VGPR budget
     for (int w : {1, 2}) run<2>(w, d_pts);               // 256-VGPR budget
