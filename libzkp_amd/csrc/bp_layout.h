@@ -189,7 +189,8 @@ inline std::vector<SlotList> targets_round(uint32_t r, uint32_t n = BP_N, uint8_
 }
 inline std::vector<SlotList> targets_ctask(uint8_t nw = NWIN, uint8_t nw64 = NWIN_U64) { return {SlotList{{BASE_B, nw64}, {BASE_BB, nw}}}; }
 // range-proof verification: one target over all 130 generators (slot index == generator index == digit row)
-inline std::vector<SlotList> targets_verify() {
+inline std::vector<SlotList> targets_verify(uint8_t nw = NWIN) {
+    const uint8_t NWIN = nw;
     SlotList t = {{BASE_B, NWIN}, {BASE_BB, NWIN}};
     for (uint32_t i = 0; i < BP_N; i++) t.push_back({(uint16_t)(BASE_G + i), NWIN});
     for (uint32_t i = 0; i < BP_N; i++) t.push_back({(uint16_t)(BASE_H + i), NWIN});

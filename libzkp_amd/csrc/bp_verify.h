@@ -14,6 +14,7 @@
 // encoding is 32 zero bytes.
 #pragma once
 #include "bp_steps.h"
+#include "edg.h"
 #include "sha256_dev.h"
 
 namespace zkp {
@@ -57,7 +58,8 @@ struct VfyView {
     uint32_t* vscal;              // [17][8][M] raw scalars of the proof points
     uint32_t* partial;            // the MSM partial array; proof-point products go to chunks var_chunk0 + p
     uint32_t var_chunk0;
-    const uint32_t* table;        // generator tables (parse step: min*B, max*B)
+    const uint32_t* table;        // generator tables (parse step: min*B, max*B): radix 2^16 in HBM (edg.h) when dig16, else the radix-1024 tables
+    uint32_t dig16 = 0;           // radix of `table` and of the fixed-base digit rows (1: the device; 0: the host emulation's small tables)
     // batch mode (random linear combination over the whole batch): rho = [8][M] per-job weights (Montgomery scalars), or
     // null for the per-job check.  With weights every coefficient is multiplied by rho_job; the generator coefficients then go to
     // fterm ([130][8][M] Montgomery scalars, summed over the jobs afterwards) instead of per-job digit rows.
@@ -131,6 +133,26 @@ ZKP_HD inline ge ge_scalarmult_raw(const ge& P, const sc& k) {
     return acc;
 }
 
+// v * B for a 64-bit v through the window tables of the basepoint (either radix: VfyView::dig16)
+ZKP_HD inline ge vfy_mul_b_u64(const VfyView& V, uint64_t v) {
+    ge acc = ge_identity();
+    const sc raw = sc_words((uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0);
+    if (V.dig16) {
+        uint32_t d[8]; sc_recode_signed65536(d, raw);
+        for (uint32_t win = 0; win < EDG_NWIN_U64; win++) {
+            const int32_t a = (int32_t)(int16_t)(d[win >> 1] >> (16 * (win & 1)));
+            if (a != 0) acc = edg_accumulate_from(acc, a, V.table, BASE_B, win);
+        }
+        return acc;
+    }
+    uint32_t d[DIGW]; sc_recode_signed1024(d, raw);
+    for (uint32_t win = 0; win < NWIN_U64; win++) {
+        const int32_t a = (int32_t)(int16_t)(d[win >> 1] >> (16 * (win & 1)));
+        if (a != 0) acc = msm_accumulate_digit(acc, a, V.table + ((size_t)BASE_B * NWIN + win) * SUBTAB_W);
+    }
+    return acc;
+}
+
 // ---- step 0: envelope framing (bulletproofs.rs:181-295 through proof_helpers.rs:12-36).  thread = envelope
 ZKP_HD inline void step_vparse(const VfyView& V, uint32_t i, const uint8_t* env, uint64_t env_off, uint32_t len, uint64_t mn, uint64_t mx) {
     const uint32_t j0 = 2 * i, j1 = 2 * i + 1;
@@ -158,16 +180,7 @@ ZKP_HD inline void step_vparse(const VfyView& V, uint32_t i, const uint8_t* env,
     if (!ge_ristretto_decode(cm, wm) || !ge_ristretto_decode(cx, wx)) return;
     if (!(n_bits == 8 || n_bits == 16 || n_bits == 32 || n_bits == 64)) return;
     // commitments of the two sub-proofs must be C - min*B and max*B - C
-    ge mb = ge_identity(), xb = ge_identity();
-    uint32_t dmn[DIGW], dmx[DIGW];
-    sc_recode_signed1024(dmn, sc_words((uint32_t)mn, (uint32_t)(mn >> 32), 0, 0, 0, 0, 0, 0));
-    sc_recode_signed1024(dmx, sc_words((uint32_t)mx, (uint32_t)(mx >> 32), 0, 0, 0, 0, 0, 0));
-    for (uint32_t win = 0; win < NWIN_U64; win++) {
-        const uint32_t* sub = V.table + ((size_t)BASE_B * NWIN + win) * SUBTAB_W;
-        const int32_t a = (int32_t)(int16_t)(dmn[win >> 1] >> (16 * (win & 1))), b = (int32_t)(int16_t)(dmx[win >> 1] >> (16 * (win & 1)));
-        if (a != 0) mb = msm_accumulate_digit(mb, a, sub);
-        if (b != 0) xb = msm_accumulate_digit(xb, b, sub);
-    }
+    const ge mb = vfy_mul_b_u64(V, mn), xb = vfy_mul_b_u64(V, mx);
     uint32_t e1[8], e2[8];
     ge_ristretto_encode(e1, ge_add(vc, ge_neg(mb)));
     ge_ristretto_encode(e2, ge_add(xb, ge_neg(vc)));
@@ -198,13 +211,7 @@ ZKP_HD inline void step_vparse_threshold(const VfyView& V, uint32_t i, const uin
     ge d, sp; uint32_t wd[8], wsp[8];
     ld_bytes_words(wd, dc, 8); ld_bytes_words(wsp, comm, 8);
     if (!ge_ristretto_decode(d, wd) || !ge_ristretto_decode(sp, wsp)) return;
-    ge tb = ge_identity();
-    uint32_t dt[DIGW];
-    sc_recode_signed1024(dt, sc_words((uint32_t)threshold, (uint32_t)(threshold >> 32), 0, 0, 0, 0, 0, 0));
-    for (uint32_t win = 0; win < NWIN_U64; win++) {
-        const int32_t a = (int32_t)(int16_t)(dt[win >> 1] >> (16 * (win & 1)));
-        if (a != 0) tb = msm_accumulate_digit(tb, a, V.table + ((size_t)BASE_B * NWIN + win) * SUBTAB_W);
-    }
+    const ge tb = vfy_mul_b_u64(V, threshold);
     uint32_t e[8];
     ge_ristretto_encode(e, ge_add(sp, ge_neg(tb)));
     for (int k = 0; k < 8; k++) if (e[k] != wd[k]) return;
@@ -282,7 +289,7 @@ ZKP_HD inline void step_vdecode(const VfyView& V, uint32_t p, uint32_t job) {
 
 // coefficient of generator `base` for this job: per-job digits, or the weighted term of the batch check
 ZKP_HD inline void st_gen_coef(const VfyView& V, uint32_t base, uint32_t job, const sc& coef) {
-    if (V.rho == nullptr) st_digits(V.digits, base, job, V.M, coef);
+    if (V.rho == nullptr) st_digits(V.digits, base, job, V.M, coef, V.dig16);
     else st_sc(V.fterm, base, job, V.M, sc_mul(coef, ld_sc(V.rho, 0, job, V.M)));
 }
 // raw scalar of proof point p (weighted in batch mode)

@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(VTB) k_rlc_fixed_sum(VfyView V, uint32_t* digi
         if (t < stride) { sc o; ZKP_UNROLL for (int k = 0; k < 8; k++) o.v[k] = lds[k * VTB + t + stride]; acc = sc_add(acc, o); }
         __syncthreads();
     }
-    if (t == 0) st_digits(digits1, g, 0, 1, acc);
+    if (t == 0) st_digits(digits1, g, 0, 1, acc, V.dig16);
 }
 void bpv_launch_rlc_points(const VfyView& V, const RlcView& R, hipStream_t st) { k_rlc_points<<<dim3((V.M + VTB - 1) / VTB, VP_NUM), VTB, 0, st>>>(V, R); }
 void bpv_launch_rlc_sort(const RlcView& R, hipStream_t st) {

@@ -1,5 +1,5 @@
 // Groth16 verification through the Fq2 virtual machine (sixth translation unit of libzkp_hip; fq2vm.h, tools/gen_fq2vm.py).
-// k_g16_pairs_vm (lane = envelope) parses the points, accumulates the public inputs and lays the three (Q, P) pairs out as the
+// k_g16_public_inputs (16 lanes per envelope) accumulates the public inputs; k_g16_pairs_vm (lane = envelope) parses the points and lays the three (Q, P) pairs out as the
 // machine's slot buffer; k_fq2vm runs a chain for 32 envelopes per workgroup on four cooperating waves -- chain A: the Miller loop of
 // (B, A); chain B: the Miller loops of (gamma, -L) and (delta, -C) on the key's line table, one shared accumulator; the subgroup check of
 // B; the final exponentiation -- and k_g16_vm_verdict reads the results.  A, B and the subgroup check run side by side.  Envelopes with a point
@@ -23,15 +23,43 @@ __device__ inline fq2 vm_get(const uint32_t* io, uint32_t n, uint32_t i, uint32_
     fq2 x; for (uint32_t k = 0; k < 10; k++) { x.c0.v[k] = io[((size_t)slot * fq2vm::FQ2_W + k) * n + i]; x.c1.v[k] = io[((size_t)slot * fq2vm::FQ2_W + 10 + k) * n + i]; }
     return x;
 }
+// The public-input point L of every envelope, PI_LANES lanes per envelope (g16_verify.h: g16_public_input_lane), the lanes' partial points
+// joined by a tree through LDS: 4 envelopes per 64-lane workgroup, so 1024 membership envelopes are 256 waves instead of 16 and an envelope's
+// chain of additions is ~10 table steps + 4 tree levels instead of ~170.  Lbuf: [30 words][n] Jacobian (infinity for a malformed envelope,
+// which k_g16_pairs_vm rejects from the same header check).
+constexpr uint32_t PI_LANES = 16, PI_ENV = 64 / PI_LANES;
+__global__ void __launch_bounds__(64) k_g16_public_inputs(int kind, const uint8_t* in, uint64_t stride, const uint32_t* len, uint32_t n, G16Vk vk, uint32_t* Lbuf) {
+    __shared__ uint32_t sh[30 * 64];
+    const uint32_t t = threadIdx.x, i = blockIdx.x * PI_ENV + t / PI_LANES, lane = t % PI_LANES;
+    g1_jac acc = jac_infinity<fq>();
+    if (i < n) {
+        const uint32_t l = len[i] <= stride ? len[i] : 0u;
+        G16Inputs h;
+        if (g16_header(kind, vk, in + (uint64_t)i * stride, l, h)) acc = g16_public_input_lane(vk, h, lane, PI_LANES);
+    }
+    for (uint32_t s = 1; s < PI_LANES; s <<= 1) {
+        for (uint32_t k = 0; k < 10; k++) { sh[k * 64 + t] = acc.X.v[k]; sh[(10 + k) * 64 + t] = acc.Y.v[k]; sh[(20 + k) * 64 + t] = acc.Z.v[k]; }
+        __syncthreads();
+        if ((lane & (2 * s - 1)) == 0) {
+            g1_jac o;
+            for (uint32_t k = 0; k < 10; k++) { o.X.v[k] = sh[k * 64 + t + s]; o.Y.v[k] = sh[(10 + k) * 64 + t + s]; o.Z.v[k] = sh[(20 + k) * 64 + t + s]; }
+            acc = jac_add(acc, o);
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && i < n) for (uint32_t k = 0; k < 10; k++) { Lbuf[(size_t)k * n + i] = acc.X.v[k]; Lbuf[(size_t)(10 + k) * n + i] = acc.Y.v[k]; Lbuf[(size_t)(20 + k) * n + i] = acc.Z.v[k]; }
+}
 // flags: 0 = a point fails to parse (verdict: reject), 1 = the generic case (all three pairs present, B finite), 2 = special
-__global__ void __launch_bounds__(64) k_g16_pairs_vm(int kind, const uint8_t* in, uint64_t stride, const uint32_t* len, uint32_t n, G16Vk vk, uint32_t* io, uint8_t* flags) {
+__global__ void __launch_bounds__(64) k_g16_pairs_vm(int kind, const uint8_t* in, uint64_t stride, const uint32_t* len, uint32_t n, G16Vk vk, const uint32_t* Lbuf, uint32_t* io, uint8_t* flags) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     const uint32_t l = len[i] <= stride ? len[i] : 0u;
     const uint8_t* env = in + (uint64_t)i * stride;
     G16Pairs o;
     g1_jac L;                                             // the public-input point stays Jacobian: chain B takes it projectively (g16_vm_pair1)
-    const bool v = kind == G16_EQUALITY ? g16_equality_pairs(vk, env, l, o, &L) : g16_membership_pairs(vk, env, l, o, &L);
+    g1_jac Lin;
+    for (uint32_t k = 0; k < 10; k++) { Lin.X.v[k] = Lbuf[(size_t)k * n + i]; Lin.Y.v[k] = Lbuf[(size_t)(10 + k) * n + i]; Lin.Z.v[k] = Lbuf[(size_t)(20 + k) * n + i]; }
+    const bool v = kind == G16_EQUALITY ? g16_equality_pairs(vk, env, l, o, &L, &Lin) : g16_membership_pairs(vk, env, l, o, &L, &Lin);
     const bool generic = v && o.present == 15u;
     flags[i] = !v ? 0 : generic ? 1 : 2;
     for (uint32_t j = 0; j < 3; j++) {
@@ -55,7 +83,7 @@ __global__ void __launch_bounds__(64) k_g16_vm_verdict(uint32_t n, const uint32_
     ok[i] = good ? 1 : 0;
 }
 
-size_t g16_vm_scratch_bytes(uint32_t n) { return (size_t)n * ((size_t)fq2vm::N_SLOTS * fq2vm::FQ2_W * 4 + 1) + 512; }          // the slot buffer, then one flag byte per envelope
+size_t g16_vm_scratch_bytes(uint32_t n) { return (size_t)n * ((size_t)fq2vm::N_SLOTS * fq2vm::FQ2_W * 4 + 30 * 4 + 1) + 512; }          // the slot buffer, the public-input points, then one flag byte per envelope
 
 int g16_vm_upload(G16VmTables& T) {          // (g16_vm_free is declared in g16_verify_launch.h)
     auto up = [](const void* src, size_t bytes, const void** dst) -> int {
@@ -118,9 +146,11 @@ void g16_launch_verify_vm(int kind, const uint8_t* d_in, uint64_t stride, const 
                           const uint32_t* d_lines, void* d_scratch, uint8_t* d_ok, uint32_t* d_special, hipStream_t st) {
     if (!n) return;
     uint32_t* io = reinterpret_cast<uint32_t*>(d_scratch);
-    uint8_t* flags = reinterpret_cast<uint8_t*>(io + (size_t)fq2vm::N_SLOTS * fq2vm::FQ2_W * n);
+    uint32_t* Lbuf = io + (size_t)fq2vm::N_SLOTS * fq2vm::FQ2_W * n;
+    uint8_t* flags = reinterpret_cast<uint8_t*>(Lbuf + (size_t)30 * n);
     const uint32_t nb = (n + 63) / 64;
-    k_g16_pairs_vm<<<nb, 64, 0, st>>>(kind, d_in, stride, d_len, n, vk, io, flags);
+    k_g16_public_inputs<<<(n + PI_ENV - 1) / PI_ENV, 64, 0, st>>>(kind, d_in, stride, d_len, n, vk, Lbuf);
+    k_g16_pairs_vm<<<nb, 64, 0, st>>>(kind, d_in, stride, d_len, n, vk, Lbuf, io, flags);
     const uint32_t K = 4, ng = (n + fq2vm::G - 1) / fq2vm::G;
     const size_t pair_words = (size_t)fq2vm::PAIR_SLOTS * fq2vm::FQ2_W * n;
     // chain: 0 = A, 1 = subgroup, 2 = finish, 3 = B (the index of its script in T.script and of its register count in REGS_K4)

@@ -137,35 +137,97 @@ ZKP_HD inline fq12 g16_pair_miller(const G16Pairs& o, uint32_t j) { return (o.pr
 ZKP_HD_NOINLINE inline bool g16_finish(const G16Vk& vk, const fq12& f0, const fq12& f1, const fq12& f2) {
     return fq12_is_one(final_exponentiation_chain(fq12_mul(fq12_mul(vk.ml_alpha_beta, f0), fq12_mul(f1, f2))));
 }
+// ---- envelope headers: what the public inputs are, before any curve arithmetic (shared by the one-lane form below and the 16-lane form)
+struct G16Inputs { uint32_t c[8]; uint32_t n; const uint8_t* set; const uint8_t* proof; };      // commitment, set size and bytes (membership), A || B || C
 // equality envelope (scheme 2, 298 bytes): public input = the embedded 32-byte commitment as an integer < r
-ZKP_HD_NOINLINE inline bool g16_equality_pairs(const G16Vk& vk, const uint8_t* env, uint32_t len, G16Pairs& o, g1_jac* Lout = nullptr) {
-    o.present = 0;
+ZKP_HD inline bool g16_equality_header(const G16Vk& vk, const uint8_t* env, uint32_t len, G16Inputs& h) {
     if (len != 298 || env[0] != 2 || env[1] != 2 || vk.n_ic != 2) return false;
     if (ld_u32_le(env + 2) != 256 || ld_u32_le(env + 6) != 32) return false;
-    uint32_t c[8]; ld_le_words(c, env + 266);
-    if (!fr_raw_lt_r(c)) return false;
-    const g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), g16_ic_mul(vk, 1, c, G16V_NWIN));
-    return g16_pairs(vk, env + 10, L, o, Lout);
+    ld_le_words(h.c, env + 266);
+    h.n = 0; h.set = nullptr; h.proof = env + 10;
+    return fr_raw_lt_r(h.c);
 }
 // membership envelope (scheme 4): payload = u32 n || n x u64 set || 256-byte proof; public inputs =
 // commitment, 64 set slots (zero padded), 64 is_real flags (snark.rs:482-492)
-ZKP_HD_NOINLINE inline bool g16_membership_pairs(const G16Vk& vk, const uint8_t* env, uint32_t len, G16Pairs& o, g1_jac* Lout = nullptr) {
-    o.present = 0;
+ZKP_HD inline bool g16_membership_header(const G16Vk& vk, const uint8_t* env, uint32_t len, G16Inputs& h) {
     if (len < 10 + 4 + 256 + 32 || env[0] != 2 || env[1] != 4 || vk.n_ic != 2 + 2 * G16_MAX_SET) return false;
     const uint32_t plen = ld_u32_le(env + 2), clen = ld_u32_le(env + 6);
     if (clen != 32 || (uint64_t)10 + plen + clen != len || plen < 4 + 256) return false;
-    const uint32_t n = ld_u32_le(env + 10);
-    if (n > G16_MAX_SET || plen != 4 + 8 * n + 256) return false;
-    uint32_t c[8]; ld_le_words(c, env + 10 + plen);
-    if (!fr_raw_lt_r(c)) return false;
-    g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), g16_ic_mul(vk, 1, c, G16V_NWIN));
-    for (uint32_t i = 0; i < n; i++) {
-        uint64_t v = 0; for (int k = 0; k < 8; k++) v |= (uint64_t)env[14 + 8 * i + k] << (8 * k);
+    h.n = ld_u32_le(env + 10);
+    if (h.n > G16_MAX_SET || plen != 4 + 8 * h.n + 256) return false;
+    ld_le_words(h.c, env + 10 + plen);
+    h.set = env + 14; h.proof = env + 14 + 8 * h.n;
+    return fr_raw_lt_r(h.c);
+}
+ZKP_HD inline bool g16_header(int kind, const G16Vk& vk, const uint8_t* env, uint32_t len, G16Inputs& h) {
+    return kind == G16_EQUALITY ? g16_equality_header(vk, env, len, h) : g16_membership_header(vk, env, len, h);
+}
+ZKP_HD inline uint64_t g16_set_element(const G16Inputs& h, uint32_t i) { uint64_t v = 0; for (int k = 0; k < 8; k++) v |= (uint64_t)h.set[8 * i + k] << (8 * k); return v; }
+// L = IC_0 + c IC_1 [+ sum_i (v_i IC_{2+i} + IC_{2+64+i})], one lane
+ZKP_HD_NOINLINE inline g1_jac g16_public_input_point(const G16Vk& vk, const G16Inputs& h) {
+    g1_jac L = jac_add(jac_from_aff(ld_ic(vk, 0)), g16_ic_mul(vk, 1, h.c, G16V_NWIN));
+    for (uint32_t i = 0; i < h.n; i++) {
+        const uint64_t v = g16_set_element(h, i);
         const uint32_t vw[8] = {(uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0};
         if (v) L = jac_add(L, vk.ic_table ? g16_ic_mul(vk, 2 + i, vw, G16V_NWIN_U64) : g1_mul_u64(ld_ic(vk, 2 + i), v));
         L = jac_madd(L, ld_ic(vk, 2 + G16_MAX_SET + i));            // is_real = 1
     }
-    return g16_pairs(vk, env + 14 + 8 * n, L, o, Lout);
+    return L;
+}
+// The same point on `nlanes` cooperating lanes (round 4: VERDICT r03 item 5).  A membership envelope's L is 26 + 8 n + 1 table steps
+// (26 windows of the commitment, 7 windows and the is_real point of each set element, IC_0): 155 of them for a 16-element set, one
+// after the other on ONE lane while a batch of 1024 envelopes occupied 16 waves of a 1024-wave chip (2.0 ms of the call's 8.5).  Here
+// lane t of the envelope takes steps t, t + nlanes, ...; the caller adds the lanes' partial points (any order: the sum is the same
+// point).  Digits are the ones g16_ic_mul walks -- a window's digit needs the carries of the windows below it, integer work that every
+// lane redoes for its own windows.  Without window tables (host emulation of a large key) lane 0 does it all.
+ZKP_HD inline int32_t g16_ic_digit(const uint32_t k[8], uint32_t w) {
+    uint32_t carry = 0; int32_t d = 0;
+    for (uint32_t j = 0; j <= w; j++) {
+        const uint32_t bit = G16V_WBITS * j, wd = bit >> 5, sh = bit & 31u;
+        uint32_t x = wd < 8 ? k[wd] >> sh : 0u;
+        if (sh + G16V_WBITS > 32 && wd + 1 < 8) x |= k[wd + 1] << (32 - sh);
+        const uint32_t dd = (x & ((1u << G16V_WBITS) - 1u)) + carry;
+        carry = dd > G16V_NENT ? 1u : 0u;
+        d = (int32_t)dd - (int32_t)(carry << G16V_WBITS);
+    }
+    return d;
+}
+ZKP_HD inline uint32_t g16_public_input_steps(const G16Inputs& h) { return G16V_NWIN + 1 + (G16V_NWIN_U64 + 1) * h.n; }
+ZKP_HD_NOINLINE inline g1_jac g16_public_input_lane(const G16Vk& vk, const G16Inputs& h, uint32_t lane, uint32_t nlanes) {
+    if (vk.ic_table == nullptr) return lane == 0 ? g16_public_input_point(vk, h) : jac_infinity<fq>();
+    g1_jac acc = jac_infinity<fq>();
+    const uint32_t S = g16_public_input_steps(h);
+    for (uint32_t s = lane; s < S; s += nlanes) {
+        uint32_t ic, w; int32_t d;
+        if (s < G16V_NWIN) { ic = 1; w = s; d = g16_ic_digit(h.c, w); }
+        else if (s == G16V_NWIN) { acc = jac_madd(acc, ld_ic(vk, 0)); continue; }
+        else {
+            const uint32_t q = s - G16V_NWIN - 1, i = q / (G16V_NWIN_U64 + 1); w = q % (G16V_NWIN_U64 + 1);
+            if (w == G16V_NWIN_U64) { acc = jac_madd(acc, ld_ic(vk, 2 + G16_MAX_SET + i)); continue; }      // is_real = 1
+            const uint64_t v = g16_set_element(h, i);
+            const uint32_t vw[8] = {(uint32_t)v, (uint32_t)(v >> 32), 0, 0, 0, 0, 0, 0};
+            ic = 2 + i; d = g16_ic_digit(vw, w);
+        }
+        if (d == 0) continue;
+        const uint32_t* e = vk.ic_table + (((size_t)ic * G16V_NWIN + w) * G16V_NENT + (uint32_t)((d < 0 ? -d : d) - 1)) * 20;
+        g1_aff q; for (int j = 0; j < 10; j++) { q.x.v[j] = e[j]; q.y.v[j] = e[10 + j]; }
+        if (d < 0) q.y = fq_neg(q.y);
+        acc = jac_madd(acc, q);
+    }
+    return acc;
+}
+// Lin != nullptr: the public-input point was accumulated elsewhere (g16_public_input_lane)
+ZKP_HD_NOINLINE inline bool g16_equality_pairs(const G16Vk& vk, const uint8_t* env, uint32_t len, G16Pairs& o, g1_jac* Lout = nullptr, const g1_jac* Lin = nullptr) {
+    o.present = 0;
+    G16Inputs h;
+    if (!g16_equality_header(vk, env, len, h)) return false;
+    return g16_pairs(vk, h.proof, Lin ? *Lin : g16_public_input_point(vk, h), o, Lout);
+}
+ZKP_HD_NOINLINE inline bool g16_membership_pairs(const G16Vk& vk, const uint8_t* env, uint32_t len, G16Pairs& o, g1_jac* Lout = nullptr, const g1_jac* Lin = nullptr) {
+    o.present = 0;
+    G16Inputs h;
+    if (!g16_membership_header(vk, env, len, h)) return false;
+    return g16_pairs(vk, h.proof, Lin ? *Lin : g16_public_input_point(vk, h), o, Lout);
 }
 // one envelope start to finish in one thread (what the three GPU kernels compute between them; used by the host emulation)
 ZKP_HD inline bool g16_verify_envelope(int kind, const G16Vk& vk, const uint8_t* env, uint32_t len) {

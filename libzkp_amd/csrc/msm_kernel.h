@@ -4,79 +4,12 @@
 #include "bp_steps.h"
 
 using namespace zkp;
-// lanes (= proofs) per MSM workgroup, digit radix and table shape are traits of the point type T (T::TB, T::NWIN, T::NENT, T::DIGW)
+// digit radix and table shape are run-time properties of the launch (MsmView); the point arithmetic is a trait of the point type T
 static constexpr int TW = 64;        // one wave per block for per-proof serial steps
 static constexpr int TB = 256;       // threads per block for (i, proof) grids
 
-// ---- variant 2 (default): LDS-DMA, templated on the point type.  The next (slot, window) sub-table is fetched
-// straight into the other half of a double-buffered LDS image with global_load_lds_dwordx4 (no staging VGPRs, no
-// ds_write) while the current window's point additions run; one barrier per window (after the issuing waves'
-// vmcnt(0)) publishes it.
-template <class T> constexpr size_t msm_lds_bytes() { return (size_t)(T::DOUBLE_BUF ? 2 : 1) * T::NENT * T::AFF_W * 4; }   // sub-table image(s), dynamic LDS
-template <class T>
-__global__ void __launch_bounds__(T::TB, T::MIN_WAVES) k_msm_dma(MsmView m, uint32_t ngroups, uint32_t nblocks) {
-#if defined(__HIP_DEVICE_COMPILE__)   // device-only builtins: keep the host-side stub instantiation empty
-    constexpr uint32_t SUB_W = T::NENT * T::AFF_W, SUB_V4 = SUB_W / 4, MSM_TB = T::TB;
-    extern __shared__ uint4 msm_lds4[];
-    uint4* const lds4_0 = msm_lds4;
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint32_t per_xcd = (nblocks + 7) / 8;
-    const uint32_t linear = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if (linear >= nblocks) return;
-    const uint32_t chunk = linear / ngroups, group = linear % ngroups;
-    const uint32_t row = group * MSM_TB + tid;
-    const bool active = row < m.rows;
-    uint32_t s = m.chunk_begin[chunk], w = m.chunk_win0[chunk], left = m.chunk_nwin[chunk], cur = 0;
-    typename T::Acc acc = m.acc_init ? T::load(m.acc_init, 0, 0, 1) : T::identity();
-#define ZKP_MSM_DMA(buf_, base_, win_)                                                                              \
-    do {                                                                                                            \
-        const uint4* src_ = reinterpret_cast<const uint4*>(m.table + ((size_t)(base_) * T::NWIN + (win_)) * SUB_W);     \
-        ZKP_UNROLL for (uint32_t q_ = 0; q_ < (SUB_V4 + MSM_TB - 1) / MSM_TB; q_++) {                               \
-            const uint32_t first_ = q_ * MSM_TB + wave * 64u;   /* wave-uniform: 64 x 16 B = 1 KiB contiguous */    \
-            if (first_ < SUB_V4)                                                                                    \
-                __builtin_amdgcn_global_load_lds(src_ + first_ + lane, lds4_0 + (buf_) * SUB_V4 + first_, 16, 0, 0);              \
-        }                                                                                                           \
-    } while (0)
-    // digit words are fetched one step ahead: the load rides under the same vmcnt(0) + barrier that publishes the sub-table
-    auto digit_word = [&](uint32_t slot, uint32_t win) -> uint32_t {
-        const uint32_t srow = m.slot_scalar ? m.slot_scalar[slot] : slot;
-        return active ? m.digits[((size_t)srow * T::DIGW + win / T::DIG_PER_WORD) * m.rows + row] : 0u;
-    };
-    if (left) ZKP_MSM_DMA(0, m.slot_base[s], w);
-    uint32_t dw = left ? digit_word(s, w) : 0u;                   // the chunk may start in the middle of a word
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    while (left) {
-        const uint32_t nwin = m.slot_nwin[s];
-        uint32_t ns = s, nw = w + 1;
-        if (nw == nwin) { ns = s + 1; nw = 0; }
-        uint32_t dnext = dw;
-        const int32_t d = T::digit(dw, w);
-        if constexpr (T::DOUBLE_BUF) {
-            if (left > 1) {
-                ZKP_MSM_DMA(cur ^ 1u, m.slot_base[ns], nw);           // lands while this window is being added
-                if ((nw % T::DIG_PER_WORD) == 0) dnext = digit_word(ns, nw);
-            }
-            if (d != 0) acc = T::accumulate(acc, d, reinterpret_cast<const uint32_t*>(lds4_0 + cur * SUB_V4));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces (and the prefetched digit word) have landed
-            __syncthreads();                                   // every wave's pieces landed; every wave is done reading `cur`
-            cur ^= 1u;
-        } else {                                               // one sub-table image (it does not fit twice): refill between windows
-            if (left > 1 && (nw % T::DIG_PER_WORD) == 0) dnext = digit_word(ns, nw);
-            if (d != 0) acc = T::accumulate(acc, d, reinterpret_cast<const uint32_t*>(lds4_0));
-            __syncthreads();                                   // every wave is done reading the image
-            if (left > 1) ZKP_MSM_DMA(0u, m.slot_base[ns], nw);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        s = ns; w = nw; left--; dw = dnext;
-    }
-#undef ZKP_MSM_DMA
-    if (active) T::store(m.partial, chunk, row, m.rows, acc);
-#else
-    (void)m; (void)ngroups; (void)nblocks;
-#endif
-}
+// (Rounds 1-3 also had k_msm_dma here: radix-1024 sub-tables streamed through LDS by DMA for 1024-lane workgroups.  Round 4 moved the last of
+// its users -- the ed25519 prover, then the verifier's fixed-base part -- to the gather kernel below and deleted it)
 
 // ---- HBM-resident tables, per-lane gathers (Groth16 key points).  The tables are sized for HBM, not for LDS: radix 2^14
 // needs 8192 entries per (key point, window) -- 512 KB for G1, 1 MB for G2, tens of GB per key in total; the shape (m.nwin, m.nent,

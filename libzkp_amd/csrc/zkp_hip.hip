@@ -1,8 +1,7 @@
 // libzkp_hip: kernels + C ABI (include/libzkp_hip.h) of the MI355X Bulletproofs prover (range / threshold / consistency
 // framings, 8- to 64-bit proofs) and, through the .inc files at the end, the host side of the Groth16, STARK, verification
 // and mixed-batch entry points.  gfx950 only.  One lane = one proof for every scalar / transcript step; the dominant
-// kernel (k_msm_dma, msm_kernel.h) streams fixed-base window sub-tables through LDS by DMA so that each table byte is
-// fetched from L2 once per 1024 proofs and the per-lane table gathers hit LDS instead of HBM/L2.
+// kernel (k_msm_gather, msm_kernel.h) walks fixed-base window tables sized for HBM, one gathered entry per lane and step.
 #include <hip/hip_runtime.h>
 #include <mutex>
 #include <memory>
@@ -144,28 +143,18 @@ __global__ void __launch_bounds__(TW, ZKP_BP_CHAIN_WAVES) k_encode(ReduceView R,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fixed-base multiscalar multiplication, lane = proof (kernel template: msm_kernel.h).
-//   grid  : nchunks * ngroups workgroups of 1024 lanes; a workgroup owns one chunk of (slot, window) steps (same
-//           generators for all its lanes) and 1024 consecutive proofs: 16 waves = 4 per SIMD, one workgroup per CU.
-//   LDS   : the 60 KB sub-table (512 affine-niels multiples of 1024^w * Base) of the current and the next step
-//           (120 KB, dynamic), filled by LDS-DMA, gathered per lane by its own signed radix-1024 digit.  Radix 1024
-//           needs 26 additions per 253-bit scalar where radix 256 needed 32; the sub-table is four times larger, which
-//           is why the workgroup is four times wider (same 60 B of table traffic per addition).
-//   XCD   : workgroups that share a chunk (hence the same sub-tables) are mapped onto the same XCD so the sub-table
-//           stays in that XCD's 4 MB L2 (blocks b and b+8 share an XCD).
+// Fixed-base multiscalar multiplication, lane = proof: k_msm_gather<EdGather> (msm_kernel.h, edg_kernels.hip) over the radix-2^16
+// tables of edg.h in HBM; 256-lane workgroups of independent waves, one chunk of (generator, window) steps each, workgroups that share
+// a chunk on one XCD.  EdMsm names the point type for the partial-sum kernel.
 struct EdMsm {      // edwards25519 affine-Niels tables, extended-coordinate accumulator (Bulletproofs path)
-    static constexpr uint32_t AFF_W = NIELS_W, ACC_W = GE_W, MIN_WAVES = 4, TB = 1024, NWIN = zkp::NWIN, NENT = zkp::NENT, DIGW = zkp::DIGW, DIG_PER_WORD = 2;
-    static constexpr bool DOUBLE_BUF = true;
-    static __device__ __forceinline__ int32_t digit(uint32_t word, uint32_t w) { return (int32_t)(int16_t)(word >> (16 * (w & 1u))); }
+    static constexpr uint32_t ACC_W = GE_W;
     using Acc = ge;
     static __device__ __forceinline__ Acc identity() { return ge_identity(); }
-    static __device__ __forceinline__ Acc accumulate(const Acc& acc, int32_t d, const uint32_t* subtab) { return msm_accumulate_digit(acc, d, subtab); }
     static __device__ __forceinline__ void store(uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows, const Acc& a) { st_ge(p, idx, row, rows, a); }
     static __device__ __forceinline__ Acc load(const uint32_t* p, uint32_t idx, uint32_t row, uint32_t rows) { return ld_ge(p, idx, row, rows); }
     static __device__ __forceinline__ Acc add(const Acc& a, const Acc& b) { return ge_add(a, b); }
 };
 
-template __global__ void k_msm_dma<EdMsm>(MsmView, uint32_t, uint32_t);
 static constexpr uint32_t ED_SUM_ROWS = 32, ED_SUM_TB = 256;      // 8 slices per row; one wave per SIMD
 template __global__ void k_sum_t<EdMsm, ED_SUM_ROWS, ED_SUM_TB, ZKP_BP_CHAIN_WAVES>(ReduceView, uint32_t*);
 
@@ -280,13 +269,12 @@ struct DevLayout {
     uint8_t* slot_nwin = nullptr;
     uint32_t nslots = 0, nchunks = 0, ntargets = 0, max_chunk_windows = 0, max_target_chunks = 0;
     uint64_t adds_per_row = 0;   // sum of nwin = point additions per proof in this launch
-    bool gather = false;         // walks the HBM-resident radix-2^16 tables (edg.h: the prover) instead of the LDS-streamed radix-1024 ones (the verifier)
     uint32_t *steps = nullptr, *chunk_step0 = nullptr;      // k_msm_gather's flat step list (make_gather_steps); only for layouts that kernel walks
 };
 // candidate chunkings of one launch type: slot-aligned chunks of 32*T windows (T = 1..8) and window-granular "even"
 // chunkings with a given chunk count; the launch picks the one whose grid best fills the resident workgroup slots
 constexpr int MAXT = 8;
-struct LayoutSet { std::vector<DevLayout> cand; uint32_t max_chunks = 0; bool gather = false; };
+struct LayoutSet { std::vector<DevLayout> cand; uint32_t max_chunks = 0; };
 
 struct SubBatch {
     hipStream_t stream = nullptr;
@@ -312,11 +300,10 @@ struct Device {
     std::mutex mu;
     bool ready = false;
     uint64_t generation = 0;            // bumped by zkp_hip_shutdown: staged batches of an earlier life own nothing any more
-    int num_cu = 256, msm_blocks_per_cu = 3;
+    int num_cu = 256;
     int cus_now = 0;                    // CUs the launches being enqueued may use (0 = all): set by the mixed-batch scheduler while it enqueues a variant on CU-masked streams
     std::vector<SubBatch> subm;         // [lane]: Bulletproofs streams + workspace confined to the Bulletproofs CU partition of a mixed batch
     hipStream_t stream = nullptr;
-    uint32_t* d_table = nullptr;        // radix-1024 tables, streamed through LDS (k_msm_dma: the verifier's fixed-base part)
     uint32_t* d_edg_table = nullptr;    // radix-2^16 tables, gathered per lane from HBM (edg.h: every MSM of the prover)
     int edg_blocks_per_cu = 3;
     // MSM chunkings: phase 1 and the inner-product rounds depend on the proofs' bit width n = 8 << w (w = 0..3); the
@@ -380,7 +367,6 @@ void prof_end(Device::KProf& K, hipStream_t st, hipEvent_t e1, uint64_t adds);
 struct Registry {
     std::mutex mu;
     std::vector<Device*> shards;
-    std::shared_ptr<std::vector<uint32_t>> host_table;      // generator window tables, kept while several shards initialise
     bool hooked = false;
 };
 Registry& registry() { static Registry* r = new Registry(); return *r; }
@@ -516,14 +502,13 @@ void free_layout(DevLayout& D) {
     (void)hipFree(D.steps); (void)hipFree(D.chunk_step0);
     D = DevLayout();
 }
-int upload_set(LayoutSet& S, const std::vector<SlotList>& targets, bool gather = false) {
-    S.gather = gather;
+// chunkings of one launch over the HBM tables of edg.h (every ed25519 MSM of the library -- prover and, since round 4, verifier -- reads them)
+int upload_set(LayoutSet& S, const std::vector<SlotList>& targets) {
     uint32_t total = 0; for (auto& t : targets) for (auto& sl : t) total += sl.second;
     auto push = [&](const MsmLayout& L) -> int {
         S.cand.emplace_back();
         const GatherShape edg_shape{EDG_NENT, EDG_NWIN * EDG_NENT, 0u, DIGW};      // (digit rows keep their 13-word pitch)
-        int rc = upload_layout(S.cand.back(), L, gather ? &edg_shape : nullptr); if (rc) return rc;
-        S.cand.back().gather = gather;
+        int rc = upload_layout(S.cand.back(), L, &edg_shape); if (rc) return rc;
         if (S.cand.back().nchunks > S.max_chunks) S.max_chunks = S.cand.back().nchunks;
         return 0;
     };
@@ -532,9 +517,9 @@ int upload_set(LayoutSet& S, const std::vector<SlotList>& targets, bool gather =
     for (uint32_t c : counts) { if (c > total || c < targets.size()) continue; int rc = push(make_layout_even(targets, c)); if (rc) return rc; }
     return 0;
 }
-void free_set(LayoutSet& S) { for (auto& d : S.cand) free_layout(d); S.cand.clear(); S.max_chunks = 0; S.gather = false; }
+void free_set(LayoutSet& S) { for (auto& d : S.cand) free_layout(d); S.cand.clear(); S.max_chunks = 0; }
 
-// Chunk size for one launch: the grid is nchunks * ceil(rows/256) workgroups, msm_blocks_per_cu * num_cu of which are
+// Chunk size for one launch: the grid is nchunks * ceil(rows/256) workgroups, edg_blocks_per_cu * num_cu of which are
 // resident at a time; cost = (#rounds of resident workgroups) * (windows per workgroup) + the serial partial-sum tail.
 const DevLayout& pick_layout(const LayoutSet& S, uint32_t rows) {
     if (g_budget_request >= 10000) {             // benchmarking knob: the even layout whose chunk count is closest to (request - 10000)
@@ -543,24 +528,21 @@ const DevLayout& pick_layout(const LayoutSet& S, uint32_t rows) {
         return S.cand[best < S.cand.size() ? best : 0];
     }
     if (g_budget_request) { int T = (int)(g_budget_request / 32); if (T < 1) T = 1; if (T > MAXT) T = MAXT; return S.cand[T - 1]; }
-    // One 1024-lane workgroup fills a CU (16 waves, 120 KB LDS), so the grid runs in strict rounds of `resident` equal
-    // workgroups (measured: 1.5 rounds cost 1.30x of 1 round, 2 rounds 1.00x with half-size chunks).  Take the window-
-    // granular layout that minimises rounds x (windows per workgroup + per-workgroup overhead) + the partial-sum work
-    // that grows with the chunk count; g_fill scales the resident count (benchmarking knob, default 1).
+    // Take the window-granular layout that minimises rounds x (windows per workgroup + per-workgroup overhead) + the partial-sum
+    // work that grows with the chunk count; g_fill scales the resident count (benchmarking knob, default 1).
     static const int fill_pct = env_int("ZKP_HIP_BP_FILL", 100);      // tuning knob: size the MSM grids for this percentage of the CUs
-    // The gather launches (S.gather: the prover) run 256-lane workgroups of four independent waves, edg_blocks_per_cu of them per CU:
+    // The gather launches run 256-lane workgroups of four independent waves, edg_blocks_per_cu of them per CU:
     // no strict rounds, but the same trade -- more chunks fill the chip and shorten a lane's chain of additions, and every chunk is one
     // more partial point per proof for k_sum_t (a 9-product addition against the 7 of a table step).
-    const uint32_t tb = S.gather ? edg_msm_rows_per_block() : EdMsm::TB;
-    const double per_cu = S.gather ? (double)dev().edg_blocks_per_cu : (double)dev().msm_blocks_per_cu;
+    const uint32_t tb = edg_msm_rows_per_block();
+    const double per_cu = (double)dev().edg_blocks_per_cu;
     const double resident = g_fill * (fill_pct / 100.0) * (double)(dev().cus_now ? dev().cus_now : dev().num_cu) * per_cu;
     const uint32_t groups = (rows + tb - 1) / tb;
     size_t best = MAXT; double best_cost = 1e300;
     for (size_t i = MAXT; i < S.cand.size(); i++) {
         const uint32_t nc = S.cand[i].nchunks;
         const double rounds = std::ceil((double)nc * groups / resident);
-        const double cost = S.gather ? rounds * ((double)S.cand[i].max_chunk_windows + 1.0) + 1.3 * S.cand[i].max_target_chunks / 8.0
-                                     : rounds * ((double)S.cand[i].max_chunk_windows + 1.5) + 0.25 * nc / 8.0;
+        const double cost = rounds * ((double)S.cand[i].max_chunk_windows + 1.0) + 1.3 * S.cand[i].max_target_chunks / 8.0;
         if (cost < best_cost) { best_cost = cost; best = i; }
     }
     return S.cand[best < S.cand.size() ? best : 0];
@@ -571,8 +553,8 @@ int ensure_family(uint32_t lg) {
     Device::Family& F = dev().fam[lg - 3];
     if (F.ready) return 0;
     int rc;
-    if ((rc = upload_set(F.p1, targets_phase1(1u << lg, EDG_NWIN, EDG_NWIN_U64), true))) return rc;
-    for (uint32_t r = 0; r < lg; r++) if ((rc = upload_set(F.rd[r], targets_round(r, 1u << lg, EDG_NWIN), true))) return rc;
+    if ((rc = upload_set(F.p1, targets_phase1(1u << lg, EDG_NWIN, EDG_NWIN_U64)))) return rc;
+    for (uint32_t r = 0; r < lg; r++) if ((rc = upload_set(F.rd[r], targets_round(r, 1u << lg, EDG_NWIN)))) return rc;
     if (F.p1.max_chunks > dev().max_chunks) dev().max_chunks = F.p1.max_chunks;
     for (uint32_t r = 0; r < lg; r++) if (F.rd[r].max_chunks > dev().max_chunks) dev().max_chunks = F.rd[r].max_chunks;
     F.ready = true;
@@ -582,26 +564,6 @@ bool bits_to_lg(uint32_t n_bits, uint32_t* lg) {     // RangeProof::prove_single
     for (uint32_t k = 3; k <= 6; k++) if (n_bits == (1u << k)) { *lg = k; return true; }
     return false;
 }
-
-// generator window tables (one-time, host; shared by every shard)
-std::shared_ptr<std::vector<uint32_t>> host_generator_tables() {
-    Registry& R = registry();
-    std::lock_guard<std::mutex> lk(R.mu);
-    if (R.host_table) return R.host_table;
-    const size_t words = (size_t)NBASE * NWIN * SUBTAB_W;
-    auto tab = std::make_shared<std::vector<uint32_t>>(words);
-    ge gens[NBASE]; host_generators(gens);
-    std::atomic<int> next{0};
-    auto work = [&]() noexcept { for (int b; (b = next.fetch_add(1)) < (int)NBASE;) host_build_table_for_base(tab->data() + (size_t)b * NWIN * SUBTAB_W, gens[b]); };   // (no allocation inside)
-    unsigned nt = std::thread::hardware_concurrency(); if (nt == 0) nt = 4; if (nt > 16) nt = 16;
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
-    R.host_table = tab;
-    return tab;
-}
-void drop_host_generator_tables() { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); R.host_table.reset(); }
 
 // The prover's tables (edg.h): 130 generators x 16 windows x 32 768 affine-Niels entries in 128-byte slots = 8.7 GB of HBM, computed on the
 // device from the 130 generators (the host derives only those: RFC 9496 one-way map, bp_layout.h) and checked slot against slot before the
@@ -663,21 +625,12 @@ int init_device() {
     if (D.ready) return 0;
     hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, D.hip_dev));
     D.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    int occ = 0;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_dma<EdMsm>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msm_lds_bytes<EdMsm>()));
-    D.msm_blocks_per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_msm_dma<EdMsm>, EdMsm::TB, msm_lds_bytes<EdMsm>()) == hipSuccess && occ > 0) D.msm_blocks_per_cu = occ;
     HIP_TRY(hipStreamCreateWithFlags(&D.stream, hipStreamNonBlocking));
-    {
-        const auto tab = host_generator_tables();
-        HIP_TRY(hipMalloc(&D.d_table, tab->size() * 4));
-        HIP_TRY(hipMemcpy(D.d_table, tab->data(), tab->size() * 4, hipMemcpyHostToDevice));
-    }
     int rc;
     if ((rc = build_edg_table())) return rc;
     D.max_chunks = 0;
-    if ((rc = upload_set(D.p2, targets_phase2(EDG_NWIN), true))) return rc;
-    if ((rc = upload_set(D.ct, targets_ctask(EDG_NWIN, EDG_NWIN_U64), true))) return rc;
+    if ((rc = upload_set(D.p2, targets_phase2(EDG_NWIN)))) return rc;
+    if ((rc = upload_set(D.ct, targets_ctask(EDG_NWIN, EDG_NWIN_U64)))) return rc;
     D.max_chunks = D.p2.max_chunks;
     if ((rc = ensure_family(6))) return rc;
     uint32_t ns = g_subbatches; if (ns <= 1) ns = (uint32_t)env_int("ZKP_HIP_BP_SUBBATCHES", 1); if (ns < 1) ns = 1; if (ns > 8) ns = 8;
@@ -831,20 +784,16 @@ int ensure_workspace(SubBatch& sb, uint32_t M, uint32_t C) {
 }
 
 int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32_t* partial, hipStream_t st) {
-    MsmView m; m.rows = rows; m.nslots = D.nslots; m.nchunks = D.nchunks; m.table = dev().d_table; m.digits = digits;
+    MsmView m; m.rows = rows; m.nslots = D.nslots; m.nchunks = D.nchunks; m.table = dev().d_edg_table; m.digits = digits;
     m.slot_base = D.slot_base; m.slot_scalar = nullptr; m.slot_nwin = D.slot_nwin; m.chunk_begin = D.chunk_begin; m.chunk_win0 = D.chunk_win0; m.chunk_nwin = D.chunk_nwin; m.partial = partial; m.acc_init = nullptr;
     hipEvent_t e1 = nullptr;
     int rc = prof_begin(dev().prof[0], st, &e1);
     if (rc) return rc;
-    if (D.gather) {
-        m.table = dev().d_edg_table; m.nwin = EDG_NWIN; m.nent = EDG_NENT; m.digw = DIGW; m.slot_ent = EDG_NWIN * EDG_NENT; m.uneven = 0;
+    {
+        m.nwin = EDG_NWIN; m.nent = EDG_NENT; m.digw = DIGW; m.slot_ent = EDG_NWIN * EDG_NENT; m.uneven = 0;
         m.steps = D.steps; m.chunk_step0 = D.chunk_step0;
         const uint32_t tb = edg_msm_rows_per_block(), ngroups = (rows + tb - 1) / tb, nblocks = D.nchunks * ngroups;
         ZKP_TRACED("k_msm_gather<EdGather>", st, edg_launch_msm(m, ngroups, nblocks, st));
-    } else {
-        const uint32_t ngroups = (rows + EdMsm::TB - 1) / EdMsm::TB, nblocks = D.nchunks * ngroups;
-        const uint32_t grid = ((nblocks + 7) / 8) * 8;
-        ZKP_TRACED("k_msm_dma<EdMsm>", st, k_msm_dma<EdMsm><<<grid, EdMsm::TB, msm_lds_bytes<EdMsm>(), st>>>(m, ngroups, nblocks));
     }
     prof_end(dev().prof[0], st, e1, D.adds_per_row * rows);
     return 0;
@@ -1116,7 +1065,6 @@ int zkp_hip_init(int device) try {
         if (!R.hooked) { R.hooked = true; (void)atexit(zkp_hip_shutdown); }
     }
     Bind bind; int rc = bind.open(d);
-    drop_host_generator_tables();
     return rc;
 } ZKP_API_CATCH_INT
 
@@ -1140,12 +1088,10 @@ int zkp_hip_init_devices(uint32_t count, const int* devices) try {
         mine = R.shards;
         if (!R.hooked) { R.hooked = true; (void)atexit(zkp_hip_shutdown); }
     }
-    (void)host_generator_tables();                     // once, before the per-shard workers need it
     std::vector<int> rcs(count, 0); std::vector<std::string> errs(count);
     std::vector<std::thread> th;
     for (uint32_t k = 0; k < count; k++) th.emplace_back([&, k]() { rcs[k] = guarded([&]() { Bind bind; return bind.open(mine[k]); }); if (rcs[k]) { try { errs[k] = t_err; } catch (...) {} } });
     for (auto& t : th) t.join();
-    drop_host_generator_tables();
     for (uint32_t k = 0; k < count; k++) if (rcs[k]) return fail(rcs[k], errs[k]);
     return 0;
 } ZKP_API_CATCH_INT
@@ -1164,7 +1110,7 @@ int zkp_hip_use_device(int shard) try {
 // left for the runtime's own exit-time teardown to trip over.  The Device objects themselves are never freed.
 void zkp_hip_shutdown(void) try {
     std::vector<Device*> shards;
-    { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); shards.swap(R.shards); R.host_table.reset(); }
+    { Registry& R = registry(); std::lock_guard<std::mutex> lk(R.mu); shards.swap(R.shards); }
     t_sel = 0;
     for (Device* d : shards) {
         std::lock_guard<std::mutex> lk(d->mu);
@@ -1187,7 +1133,6 @@ void zkp_hip_shutdown(void) try {
             vec->clear();
         }
         d->cus_now = 0;
-        (void)hipFree(d->d_table); d->d_table = nullptr;
         release_edg_table();
         free_set(d->p2); free_set(d->ct);
         for (auto& F : d->fam) { free_set(F.p1); for (auto& s : F.rd) free_set(s); F.ready = false; }

@@ -57,6 +57,27 @@ int emul_g16_witness_qap(int kind, uint64_t value, const uint64_t* set_vals, uin
 
 // Groth16 verification of one envelope (kind 0 equality / 1 membership) under a verifying key given as raw affine
 // coordinates: alpha (16 words), beta / gamma / delta (32 each), ic (n_ic x 16)
+// window tables of one gamma_abc point, as k_g16_build_table builds them (the device builder's batched conversion): windows 0 .. nwin - 1
+static void build_ic_windows(uint32_t* tab, uint32_t i, const g1_aff& p, uint32_t nwin) {
+    g1_jac q = jac_from_aff(p);
+    for (uint32_t w = 0; w < nwin; w++) {
+        g1_jac acc = q;
+        for (uint32_t e0 = 0; e0 < G16V_NENT; e0 += 8) {
+            g1_jac pts[8]; fq zp[8];
+            for (uint32_t k = 0; k < 8; k++) { pts[k] = acc; acc = jac_add(acc, q); zp[k] = k ? f_mul(zp[k - 1], pts[k].Z) : pts[k].Z; }
+            fq inv = f_inv(zp[7]);
+            for (int k = 7; k >= 0; k--) {
+                const fq zi = k ? f_mul(inv, zp[k - 1]) : inv;
+                if (k) inv = f_mul(inv, pts[k].Z);
+                const fq zi2 = f_sq(zi);
+                g1_aff a; a.x = f_mul(pts[k].X, zi2); a.y = f_mul(pts[k].Y, f_mul(zi2, zi));
+                uint32_t* dst = tab + (((size_t)i * G16V_NWIN + w) * G16V_NENT + e0 + k) * 20;
+                for (int j = 0; j < 10; j++) { dst[j] = a.x.v[j]; dst[10 + j] = a.y.v[j]; }
+            }
+        }
+        for (uint32_t k = 0; k < G16V_WBITS; k++) q = jac_dbl(q);
+    }
+}
 // mode 0: g16_verify.h's lane-per-chain code; mode 4: the Fq2 machine (fq2vm.h) with its tables (four waves per chain),
 // every round's streams executed as the device executes them.  Returns the verdict, or 2 when the machine leaves the envelope to the
 // lane-per-chain path (a point at infinity in the proof).
@@ -71,26 +92,7 @@ static int verify_with(int mode, int kind, const uint8_t* env, uint32_t len, con
     std::vector<uint32_t> tab;
     if (n_ic <= 2) {
         tab.resize((size_t)n_ic * G16V_NWIN * G16V_NENT * 20);
-        for (uint32_t i = 0; i < n_ic; i++) {
-            g1_jac q = jac_from_aff(g1(ic + 16 * i));
-            for (uint32_t w = 0; w < G16V_NWIN; w++) {
-                g1_jac acc = q;
-                for (uint32_t e0 = 0; e0 < G16V_NENT; e0 += 8) {          // the device builder's batched conversion (k_g16_build_table)
-                    g1_jac pts[8]; fq zp[8];
-                    for (uint32_t k = 0; k < 8; k++) { pts[k] = acc; acc = jac_add(acc, q); zp[k] = k ? f_mul(zp[k - 1], pts[k].Z) : pts[k].Z; }
-                    fq inv = f_inv(zp[7]);
-                    for (int k = 7; k >= 0; k--) {
-                        const fq zi = k ? f_mul(inv, zp[k - 1]) : inv;
-                        if (k) inv = f_mul(inv, pts[k].Z);
-                        const fq zi2 = f_sq(zi);
-                        g1_aff a; a.x = f_mul(pts[k].X, zi2); a.y = f_mul(pts[k].Y, f_mul(zi2, zi));
-                        uint32_t* dst = tab.data() + (((size_t)i * G16V_NWIN + w) * G16V_NENT + e0 + k) * 20;
-                        for (int j = 0; j < 10; j++) { dst[j] = a.x.v[j]; dst[10 + j] = a.y.v[j]; }
-                    }
-                }
-                for (uint32_t k = 0; k < G16V_WBITS; k++) q = jac_dbl(q);
-            }
-        }
+        for (uint32_t i = 0; i < n_ic; i++) build_ic_windows(tab.data(), i, g1(ic + 16 * i), G16V_NWIN);
         vk.ic_table = tab.data();
     }
     if (mode == 0) {
@@ -141,4 +143,26 @@ int emul_g16_verify(int kind, const uint8_t* env, uint32_t len, const uint32_t* 
                     uint32_t n_ic, const uint32_t* ic) { return verify_with(0, kind, env, len, alpha, beta, gamma, delta, n_ic, ic); }
 int emul_g16_verify_vm(int waves, int kind, const uint8_t* env, uint32_t len, const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma, const uint32_t* delta,
                        uint32_t n_ic, const uint32_t* ic) { return verify_with(4, kind, env, len, alpha, beta, gamma, delta, n_ic, ic); }
+// The public-input point of an envelope on `nlanes` cooperating lanes (g16_public_input_lane: what k_g16_public_inputs runs, window tables
+// built as the device builds them) against the one-lane form without tables.  1: the lanes' partial points sum to the same point; 0: they
+// do not; -1: the header is refused.
+int emul_g16_public_input_lanes(int kind, const uint8_t* env, uint32_t len, uint32_t n_ic, const uint32_t* ic, uint32_t nlanes) {
+    auto g1 = [](const uint32_t* w) { return g1_aff{fq_from_raw(w), fq_from_raw(w + 8)}; };
+    std::vector<uint32_t> icm((size_t)n_ic * 20);
+    for (uint32_t i = 0; i < n_ic; i++) { const g1_aff p = g1(ic + 16 * i); for (int k = 0; k < 10; k++) { icm[20 * i + k] = p.x.v[k]; icm[20 * i + 10 + k] = p.y.v[k]; } }
+    G16Vk vk; vk.n_ic = n_ic; vk.ic = icm.data(); vk.ic_table = nullptr;
+    G16Inputs h;
+    if (!g16_header(kind, vk, env, len, h)) return -1;
+    const g1_jac want = g16_public_input_point(vk, h);
+    std::vector<uint32_t> tab((size_t)n_ic * G16V_NWIN * G16V_NENT * 20, 0u);          // only the windows the envelope's scalars reach are filled
+    build_ic_windows(tab.data(), 1, g1(ic + 16), G16V_NWIN);
+    for (uint32_t i = 0; i < h.n; i++) build_ic_windows(tab.data(), 2 + i, g1(ic + 16 * (2 + i)), G16V_NWIN_U64);
+    vk.ic_table = tab.data();
+    g1_jac sum = jac_infinity<fq>();
+    for (uint32_t lane = nlanes; lane-- > 0;) sum = jac_add(g16_public_input_lane(vk, h, lane, nlanes), sum);
+    g1_aff a, b;
+    const bool fa = jac_to_aff(a, want), fb = jac_to_aff(b, sum);
+    if (fa != fb) return 0;
+    return !fa || (fq_eq(a.x, b.x) && fq_eq(a.y, b.y)) ? 1 : 0;
+}
 }

@@ -330,6 +330,34 @@ def test_groth16_verifier_verdicts_equal_oracle(libs):
         assert bool(lib.emul_g16_verify(1, bytes(bad), len(bad), *vm)) == g.verify_membership(bytes(bad), emb, SS) is False, pos
 
 
+def test_public_input_point_on_cooperating_lanes_equals_the_one_lane_sum(libs):
+    """g16_public_input_lane (what k_g16_public_inputs runs: the table steps of one envelope dealt to 16 lanes, window tables as the device
+    builds them) against the one-lane accumulation without tables: equality, membership sets of 1 / 5 / 64 elements with 64-bit extremes,
+    other lane counts, and the headers that are refused."""
+    _, lib = libs
+    SS = bytes(range(32))
+    seed = bytes(range(9, 41))
+    pk = g.equality_key(SS)
+    va = _vk_args(pk)
+    v = 2**63 + 12345
+    cm = g.commit_value_snark(v)
+    r_, s_ = g.draw_fr(seed, 0x47313600, 0), g.draw_fr(seed, 0x47313600, 1)
+    env = g.envelope(2, g.prove_with_trapdoor(pk, g.equality_circuit(v, v, int.from_bytes(cm, "little")), r_, s_), cm)
+    for lanes in (1, 3, 16, 64):
+        assert lib.emul_g16_public_input_lanes(0, env, len(env), va[4], va[5], lanes) == 1
+    assert lib.emul_g16_public_input_lanes(0, env[:-1], len(env) - 1, va[4], va[5], 16) == -1
+    top = bytearray(env); top[266:298] = (g.R).to_bytes(32, "little")          # commitment = r: not a canonical scalar
+    assert lib.emul_g16_public_input_lanes(0, bytes(top), len(top), va[4], va[5], 16) == -1
+    pkm = g.membership_key(SS)
+    vm = _vk_args(pkm)
+    for the_set in ([7], [10, 20, 25, 0, 2**64 - 1], [3 * i + 1 for i in range(63)] + [2**64 - 1]):
+        envm = g.prove_membership(the_set[0], the_set, SS, seed)
+        for lanes in ((16,) if len(the_set) > 5 else (16, 5)):
+            assert lib.emul_g16_public_input_lanes(1, envm, len(envm), vm[4], vm[5], lanes) == 1, (len(the_set), lanes)
+    bad = bytearray(envm); bad[10] = 65                                          # n past the circuit's 64 slots
+    assert lib.emul_g16_public_input_lanes(1, bytes(bad), len(bad), vm[4], vm[5], 16) == -1
+
+
 def test_fq2_machine_verdicts_equal_the_lane_per_chain_verifier(libs):
     """fq2vm.h + the generated tables (tools/gen_fq2vm.py), executed on the host round by round (four waves per chain, two
     half-waves each), against g16_verify.h and the oracle on the same envelopes: valid, a flipped bit in every region, ark's flag rules."""

@@ -46,6 +46,18 @@ mp = z.prove_membership_batch([s[3] for s in sets], sets)
 dt, ok = best(lambda: z.verify_membership_batch(mp, sets))
 assert all(ok)
 out["membership"] = {"n": m, "set": 16, "ms": round(dt * 1e3, 2), "envelopes_per_s": round(m / dt)}
+ml = len(mp[0]); mbuf = np.zeros((m, ml), dtype=np.uint8); mlens = np.full(m, ml, dtype=np.uint32); mok = np.zeros(m, dtype=np.uint8)
+for i, e in enumerate(mp): mbuf[i] = np.frombuffer(e, dtype=np.uint8)
+dt, _ = best(lambda: _native.check(L.zkp_hip_verify_membership_batch(m, P(mbuf), ml, P(mlens), P(mok)), "verify"))
+assert mok.all()
+out["membership"]["c_abi_ms"] = round(dt * 1e3, 2); out["membership"]["c_abi_envelopes_per_s"] = round(m / dt)
+if "--sweep" in sys.argv:
+    out["membership_sweep"] = {}
+    for m2 in (4096, 16384):
+        big = np.ascontiguousarray(mbuf[np.arange(m2) % m]); bl = np.full(m2, ml, dtype=np.uint32); bok = np.zeros(m2, dtype=np.uint8)
+        dt, _ = best(lambda: _native.check(L.zkp_hip_verify_membership_batch(m2, P(big), ml, P(bl), P(bok)), "verify"), reps=3)
+        assert bok.all()
+        out["membership_sweep"][str(m2)] = {"c_abi_ms": round(dt * 1e3, 2), "c_abi_envelopes_per_s": round(m2 / dt)}
 if "--sweep" in sys.argv:
     out["equality_sweep"] = {}
     for m2 in (1024, 16384, 65536):
