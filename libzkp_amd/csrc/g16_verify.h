@@ -13,6 +13,7 @@ namespace zkp {
 // verifying key in device memory (built by the host from the loaded proving key, which starts with the vk)
 struct G16Vk {
     g2_aff gamma, delta;
+    g2_aff beta;                   // B of the batch check's virtual envelope (g16_rlc.h); the window tables carry alpha as point n_ic
     fq12 ml_alpha_beta;            // Miller loop value of (beta, -alpha): the constant factor of the check
     uint32_t n_ic;                 // gamma_abc_g1 length (1 + public inputs)
     const uint32_t* ic;            // [n_ic][20] affine points, Montgomery limbs

@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE: host run of the Groth16 witness + QAP steps (the per-proof work before the MSMs) so the no-GPU
 // tier can compare the full assignment z and the quotient coefficients h with the oracle.
 #include "../../libzkp_amd/csrc/g16_circuit.h"
-#include "../../libzkp_amd/csrc/g16_verify.h"
+#include "../../libzkp_amd/csrc/g16_rlc.h"
 #include "../../libzkp_amd/csrc/fq2vm.h"
 #include <vector>
 using namespace zkp;
@@ -164,5 +164,19 @@ int emul_g16_public_input_lanes(int kind, const uint8_t* env, uint32_t len, uint
     const bool fa = jac_to_aff(a, want), fb = jac_to_aff(b, sum);
     if (fa != fb) return 0;
     return !fa || (fq_eq(a.x, b.x) && fq_eq(a.y, b.y)) ? 1 : 0;
+}
+// g16_rlc.h: one pairing check for `count` envelopes (rows of `envs`, `stride` bytes apart) under the weights rho (4 words each), on the
+// lane-per-chain pairing code.  1 accepted, 0 rejected, 2 left to the per-envelope check.
+int emul_g16_rlc(int kind, uint32_t count, const uint8_t* envs, uint32_t stride, const uint32_t* lens, const uint32_t* rho, const uint32_t* alpha, const uint32_t* beta,
+                 const uint32_t* gamma, const uint32_t* delta, uint32_t n_ic, const uint32_t* ic) {
+    auto g1 = [](const uint32_t* w) { return g1_aff{fq_from_raw(w), fq_from_raw(w + 8)}; };
+    auto g2 = [](const uint32_t* w) { return g2_aff{fq2{fq_from_raw(w), fq_from_raw(w + 8)}, fq2{fq_from_raw(w + 16), fq_from_raw(w + 24)}}; };
+    std::vector<uint32_t> icm((size_t)n_ic * 20);
+    for (uint32_t i = 0; i < n_ic; i++) { const g1_aff p = g1(ic + 16 * i); for (int k = 0; k < 10; k++) { icm[20 * i + k] = p.x.v[k]; icm[20 * i + 10 + k] = p.y.v[k]; } }
+    G16Vk vk; vk.gamma = g2(gamma); vk.delta = g2(delta); vk.beta = g2(beta); vk.n_ic = n_ic; vk.ic = icm.data(); vk.ic_table = nullptr;
+    vk.ml_alpha_beta = miller_loop(g2(beta), aff_neg(g1(alpha)));
+    std::vector<const uint8_t*> ptr(count);
+    for (uint32_t j = 0; j < count; j++) ptr[j] = envs + (size_t)stride * j;
+    return g16_rlc_check(kind, vk, g1(alpha), g2(beta), count, ptr.data(), lens, rho);
 }
 }

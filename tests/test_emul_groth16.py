@@ -358,6 +358,48 @@ def test_public_input_point_on_cooperating_lanes_equals_the_one_lane_sum(libs):
     assert lib.emul_g16_public_input_lanes(1, bytes(bad), len(bad), vm[4], vm[5], 16) == -1
 
 
+def test_one_pairing_check_for_a_batch_accepts_valid_envelopes_and_rejects_a_tampered_one(libs):
+    """g16_rlc.h on the host: the weighted batch check (one product of Miller loops on (B_j, rho_j A_j), one virtual envelope for gamma, delta
+    and beta) accepts envelopes the oracle's verifier accepts, rejects the batch when one commitment / one proof element is swapped for
+    another valid one, and hands envelopes it does not take (refused header, point at infinity) back to the per-envelope path."""
+    _, lib = libs
+    SS = bytes(range(32))
+    rnd = random.Random(5)
+    pk = g.equality_key(SS)
+    va = _vk_args(pk)
+    envs = []
+    for k in range(3):
+        seed = bytes([k + 1]) * 32
+        v = rnd.randrange(2**64)
+        cm = g.commit_value_snark(v)
+        envs.append(g.envelope(2, g.prove_with_trapdoor(pk, g.equality_circuit(v, v, int.from_bytes(cm, "little")), g.draw_fr(seed, 0x47313600, 0), g.draw_fr(seed, 0x47313600, 1)), cm))
+        assert g.verify_equality_with_commitment(envs[-1], cm, SS)
+
+    def check(kind, batch, args):
+        n = len(batch); stride = max(len(e) for e in batch)
+        buf = b"".join(e + bytes(stride - len(e)) for e in batch)
+        lens = (ctypes.c_uint32 * n)(*[len(e) for e in batch])
+        rho = (ctypes.c_uint32 * (4 * n))(*[rnd.randrange(1, 2**32) for _ in range(4 * n)])
+        return lib.emul_g16_rlc(kind, n, buf, stride, lens, rho, *args)
+
+    assert check(0, envs, va) == 1
+    assert check(0, envs[:1], va) == 1
+    swapped = [envs[0][:266] + envs[1][266:], envs[1], envs[2]]                      # a valid proof under another envelope's commitment
+    assert check(0, swapped, va) == 0
+    crossed = [envs[0][:10] + envs[1][10:74] + envs[0][74:], envs[1], envs[2]]       # A of another (valid) proof
+    assert check(0, crossed, va) == 0
+    inf = bytearray(envs[2]); inf[10:74] = bytes(63) + bytes([0x40])                  # A at infinity: a valid encoding the fast path does not take
+    assert check(0, [envs[0], bytes(inf)], va) == 2
+    assert check(0, [envs[0], envs[1][:-1]], va) == 2
+    pkm = g.membership_key(SS)
+    vm = _vk_args(pkm)
+    m1 = g.prove_membership(25, [10, 20, 25, 30, 2**40], SS, bytes(range(3, 35)))
+    m2 = g.prove_membership(2**64 - 1, [2**64 - 1, 0, 7], SS, bytes(range(4, 36)))
+    assert check(1, [m1, m2], vm) == 1
+    bad = bytearray(m2); bad[14 + 8] ^= 1                                              # a set element of the second envelope
+    assert check(1, [m1, bytes(bad)], vm) == 0
+
+
 def test_fq2_machine_verdicts_equal_the_lane_per_chain_verifier(libs):
     """fq2vm.h + the generated tables (tools/gen_fq2vm.py), executed on the host round by round (four waves per chain, two
     half-waves each), against g16_verify.h and the oracle on the same envelopes: valid, a flipped bit in every region, ark's flag rules."""

@@ -370,3 +370,77 @@ def test_groth16_machine_batch_sizes(hip):
             else:
                 blobs.append(proofs[i]); want.append(True)
         assert api._verify_snark_envelopes(0, blobs) == want, n
+
+
+_G16_BATCH_CHILD = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import libzkp_amd.api as api
+gold = os.path.join(sys.argv[1], "tests", "golden")
+for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")):
+    api.install_proving_key(kind, open(os.path.join(gold, name), "rb").read())
+out = []
+for kind, hexes in json.load(open(sys.argv[2])):
+    try:
+        out.append(api._verify_snark_envelopes(kind, [bytes.fromhex(h) for h in hexes]))
+    except Exception as e:
+        out.append("error: " + str(e))
+print(json.dumps(out))
+"""
+
+
+def test_groth16_one_pairing_check_per_batch_gives_the_per_envelope_verdicts(hip, tmp_path):
+    """The batch check (g16_rlc.h; by default for batches of 8192 envelopes and more, here forced for every size in child processes):
+    with ZKP_HIP_G16_BATCH_VERIFY_ONLY (no second, per-envelope pass) all-valid batches of 1 / 33 / 150 equality and 12 membership
+    envelopes are accepted by the single check and every batch with a tampered or special envelope is refused by it; without that
+    switch the verdicts of every batch equal the per-envelope path's, bad envelopes named one by one."""
+    import json, os, subprocess, sys
+    import libzkp_amd as z
+    import libzkp_amd.api as api
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = os.path.join(root, "tests", "golden")
+    for kind, name in ((0, "equality_mimc_pk.bin"), (1, "membership_mimc_pk.bin")):
+        api.install_proving_key(kind, open(os.path.join(gold, name), "rb").read())
+    rng = np.random.default_rng(404)
+    vals = [int(x) for x in rng.integers(0, 2**63, 150, dtype=np.uint64)]
+    proofs = z.prove_equality_batch(vals, vals)
+    sets = [[int(x) for x in rng.integers(0, 2**64, int(rng.integers(1, 65)), dtype=np.uint64)] for _ in range(12)]
+    sets[3] = [0, 2**64 - 1, 5]
+    mp = z.prove_membership_batch([s[i % len(s)] for i, s in enumerate(sets)], sets)
+    flipped = list(proofs[:40])
+    for i in (0, 7, 39):
+        b = bytearray(flipped[i]); b[30 + i] ^= 2; flipped[i] = bytes(b)
+    swapped = list(proofs[:33]); swapped[5] = proofs[5][:266] + proofs[6][266:]              # a valid proof under another commitment
+    inf = list(proofs[:9]); b = bytearray(inf[4]); b[10:74] = bytes(63) + b"\x40"; inf[4] = bytes(b)
+    short = list(proofs[:5]); short[2] = short[2][:-1]
+    mbad = list(mp); b = bytearray(mbad[8]); b[14] ^= 1; mbad[8] = bytes(b)                    # a set element
+    good = [(0, proofs[:1]), (0, proofs[:33]), (0, proofs), (1, mp), (1, mp[:1])]
+    bad = [(0, flipped), (0, swapped), (0, inf), (0, short), (1, mbad)]
+    f = tmp_path / "batches.json"
+    f.write_text(json.dumps([[k, [e.hex() for e in b]] for k, b in good + bad]))
+
+    def child(extra):
+        env = dict(os.environ, ZKP_HIP_G16_BATCH_VERIFY_MIN="1", **extra)
+        out = subprocess.run([sys.executable, "-c", _G16_BATCH_CHILD, root, str(f)], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    only = child({"ZKP_HIP_G16_BATCH_VERIFY_ONLY": "1"})
+    for (k, b), got in zip(good, only[:len(good)]):
+        assert got == [True] * len(b), (k, len(b), got if isinstance(got, str) else got.count(False))
+    both = child({})
+    want = [api._verify_snark_envelopes(k, b) for k, b in good + bad]                         # this process: batches this small take the per-envelope path
+    assert both == want
+    # tampering that leaves every point a valid group element reaches the pairing product and must fail the single check; a flipped bit
+    # that breaks an encoding, or a refused header, removes that envelope alone (no pairing work) and the check of the others stands
+    for got in only[len(good) + 1:len(good) + 3] + only[-1:]:
+        assert isinstance(got, str) and "batch check did not stand" in got, got
+    assert only[len(good) + 3] == [True, True, False, True, True] == want[len(good) + 3]
+    assert only[len(good)] == want[len(good)] or (isinstance(only[len(good)], str) and "batch check did not stand" in only[len(good)])
+    assert want[5].count(False) == 3 and want[6].count(False) == 1 and want[7].count(False) == 1 and want[9].count(False) == 1
+    # default switches, this process: 8200 envelopes take the batch check (threshold 8193), and one envelope under its neighbour's commitment
+    # sends the batch to the per-envelope pass, which names it
+    big = [proofs[i % 150] for i in range(8200)]
+    assert api._verify_snark_envelopes(0, big) == [True] * 8200
+    big[5000] = big[5000][:266] + big[5001][266:]
+    got = api._verify_snark_envelopes(0, big)
+    assert got.count(False) == 1 and got[5000] is False

@@ -60,9 +60,17 @@ if "--sweep" in sys.argv:
         out["membership_sweep"][str(m2)] = {"c_abi_ms": round(dt * 1e3, 2), "c_abi_envelopes_per_s": round(m2 / dt)}
 if "--sweep" in sys.argv:
     out["equality_sweep"] = {}
-    for m2 in (1024, 16384, 65536):
+    for m2 in (1024, 8192, 16384, 65536):
         batch = [ep[i % n] for i in range(m2)]
         dt, ok = best(lambda: api._verify_snark_envelopes(0, batch), reps=3)
         assert all(ok)
         out["equality_sweep"][str(m2)] = {"ms": round(dt * 1e3, 2), "envelopes_per_s": round(m2 / dt)}
+        big = np.ascontiguousarray(buf[np.arange(m2) % n]); bl = np.full(m2, 298, dtype=np.uint32); bok = np.zeros(m2, dtype=np.uint8)
+        dt, _ = best(lambda: _native.check(L.zkp_hip_verify_equality_batch(m2, P(big), 298, P(bl), P(bok)), "verify"), reps=3)
+        assert bok.all()
+        out["equality_sweep"][str(m2)].update({"c_abi_ms": round(dt * 1e3, 2), "c_abi_envelopes_per_s": round(m2 / dt)})
+        big[m2 // 3, 266:298] = big[m2 // 3 + 1, 266:298]       # one envelope under its neighbour's commitment: the batch check fails, every envelope is verified again
+        dt, _ = best(lambda: _native.check(L.zkp_hip_verify_equality_batch(m2, P(big), 298, P(bl), P(bok)), "verify"), reps=2)
+        assert bok.sum() == m2 - 1 and not bok[m2 // 3]
+        out["equality_sweep"][str(m2)]["c_abi_ms_with_one_tampered"] = round(dt * 1e3, 2)
 print(json.dumps(out))
