@@ -25,7 +25,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with
   cpu_baseline   oracle/c's process_batch port (OpenMP over ops, like rayon) on a bounded sample of the same ops.
 and at N = 1, beside the contract's keys: host_buffers, two_batches_in_flight, other_configs_staged (C2 / C3 / C4 on their own),
 batch_size_sweep (the mixed batch at 512 ... 16 384 ops) with predicted_strong_scaling (what one 16 384-op batch over N GPUs can reach, from
-this one GPU's step times), g16_table_radix / g16_table_bytes (which key tables produced `value`) and verification_c_abi (4096 Groth16 equality envelopes and 4096 range envelopes through the C ABI).
+this one GPU's step times), g16_table_radix / g16_table_bytes (which key tables produced `value`) and verification_c_abi (4096 Groth16 equality envelopes and 4096 range envelopes through the C ABI, and 65 536 equality envelopes through the one-pairing-check path).
 The timed region runs with the library's per-launch event profiling OFF; the launch durations behind `roofline` come from a second
 pass of the same K steps with it on (`profiled_pass` holds that pass's step time: the cost of the instrumentation is visible).
 """
@@ -425,8 +425,14 @@ def main():
             _native.check(L.zkp_hip_prove_range_batch(nv, P(rv), P(rmn), P(rmx), 64, P(rseed), P(rout), 1478, P(rlen), P(rst)), "prove_range")
             t_vr = timed(lambda: _native.check(L.zkp_hip_verify_range_batch(nv, P(rout), 1478, P(rlen), P(rmn), P(rmx), P(vok)), "verify_range"), 5)
             assert vok.all()
+            nbig = 65536                                             # above 8192 envelopes: one pairing check per call (g16_rlc.h)
+            bbuf = np.ascontiguousarray(vbuf[np.arange(nbig) % nv]); blen = np.full(nbig, 298, dtype=np.uint32); bok = np.zeros(nbig, dtype=np.uint8)
+            t_vb = timed(lambda: _native.check(L.zkp_hip_verify_equality_batch(nbig, P(bbuf), 298, P(blen), P(bok)), "verify_equality"), 3)
+            assert bok.all()
             extra["verification_c_abi"] = {"equality_4096": {"envelopes_per_s": nv / t_ve, "ms_per_batch": t_ve * 1e3}, "range_4096": {"envelopes_per_s": nv / t_vr, "ms_per_batch": t_vr * 1e3},
-                                           "note": "host buffers in, verdict bytes out; Groth16 on the Fq2 machine (DESIGN 6d); not part of the contract's value"}
+                                           "equality_65536_one_pairing_check": {"envelopes_per_s": nbig / t_vb, "ms_per_batch": t_vb * 1e3},
+                                           "note": "host buffers in, verdict bytes out; Groth16 on the Fq2 machine (DESIGN 6d), batches above 8192 envelopes through one "
+                                                   "weighted pairing check (DESIGN R4.8); not part of the contract's value"}
         except Exception as e:  # noqa: BLE001
             extra["verification_leg_error"] = repr(e)[:400]
     L.zkp_hip_batch_free(h)

@@ -156,7 +156,12 @@ int emul_g16_public_input_lanes(int kind, const uint8_t* env, uint32_t len, uint
     const g1_jac want = g16_public_input_point(vk, h);
     std::vector<uint32_t> tab((size_t)n_ic * G16V_NWIN * G16V_NENT * 20, 0u);          // only the windows the envelope's scalars reach are filled
     build_ic_windows(tab.data(), 1, g1(ic + 16), G16V_NWIN);
-    for (uint32_t i = 0; i < h.n; i++) build_ic_windows(tab.data(), 2 + i, g1(ic + 16 * (2 + i)), G16V_NWIN_U64);
+    for (uint32_t i = 0; i < h.n; i++) {
+        const uint64_t v = g16_set_element(h, i);
+        uint32_t bits = 0; while (bits < 64 && (v >> bits) != 0) bits++;
+        const uint32_t nw = bits / G16V_WBITS + 2;          // the windows a value of that size can reach (the signed digits carry one window up)
+        build_ic_windows(tab.data(), 2 + i, g1(ic + 16 * (2 + i)), nw < G16V_NWIN_U64 ? nw : G16V_NWIN_U64);
+    }
     vk.ic_table = tab.data();
     g1_jac sum = jac_infinity<fq>();
     for (uint32_t lane = nlanes; lane-- > 0;) sum = jac_add(g16_public_input_lane(vk, h, lane, nlanes), sum);

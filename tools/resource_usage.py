@@ -34,7 +34,7 @@ def main():
     for r, n in zip(rows, names):
         lines.append("| %s | `%s` | %s | %s | %s | %s | %s | %s | %s |" % (r["unit"], n, r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("VGPRs Spill"),
                                                                        r.get("ScratchSize"), r.get("LDS Size"), r.get("Occupancy")))
-    lines += ["", "Dynamic LDS is not in these figures: k_msm_dma<EdMsm> 120 KB and k_g16_qap 54 / 108 KB (launch-time), which is what limits those "
+    lines += ["", "Dynamic LDS is not in these figures: k_fq2vm 41-159 KB per chain and k_g16_qap 18 / 36 KB (launch-time), which is what limits those "
               "kernels to one workgroup per CU.  k_msm_gather<G1Msm / G2Msm> (the Groth16 MSMs) use no LDS."]
     open(out, "w").write("\n".join(lines) + "\n")
 
