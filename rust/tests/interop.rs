@@ -21,6 +21,11 @@
 //!      kernel are covered by claims 1 and 4, whose envelopes they now produce;
 //!   7. (round 4) Groth16 envelopes with a point at infinity -- crafted from a reference envelope, the encodings ark-serialize accepts --
 //!      get the SAME verdict from the reference and from the HIP verifiers (they leave the Fq2 machine for the lane-per-chain kernels).
+//!   8. (round 4) one pairing check per batch (libzkp_amd/csrc/g16_rlc.h): 8200 reference-made equality envelopes in ONE call -- above the
+//!      library's threshold of 8193 -- are all accepted; with one of them put under another's commitment the call names exactly that
+//!      envelope, as the reference's `verify_equality` does for it.  (Run the whole test once more with `ZKP_HIP_G16_BATCH_VERIFY_MIN=1` --
+//!      read once per process -- to send the single-envelope calls of claims 2 and 7 through the batch check as well.)  The 16-lane
+//!      public-input accumulation and the verifier's HBM generator tables are what claims 2 and 7 run on now.
 //! and what it writes into $LIBZKP_HIP_VECTORS (consumed by tests/test_reference_vectors.py, which skips while the directory is empty):
 //!   reference_envelopes.json   envelopes made by the reference            -> our verifiers must keep accepting them
 //!   hip_envelopes.json         inputs + seeds + envelopes made on the GPU that the reference accepted -> our prover must keep producing exactly them
@@ -223,6 +228,27 @@ fn hip_backend_and_reference_accept_each_other() {
         specials.truncate(specials.len() - 2);
         specials.push_str("\n]\n");
         std::fs::write(dir.join("special_envelopes.json"), specials).unwrap();
+    }
+
+    // ---- 8. one pairing check per batch: many reference envelopes in one call; the verdicts are the reference's, one by one
+    {
+        let n = 8200usize;                                           // above the default threshold (8193): the batch check runs first
+        let mut envs: Vec<Vec<u8>> = Vec::with_capacity(64);
+        for v in 0..64u64 { envs.push(equality_proof::prove_equality(1000 + v, 1000 + v).expect("reference prove_equality")); }
+        let width = envs[0].len();
+        let mut buf = vec![0u8; n * width];
+        for j in 0..n { buf[j * width..(j + 1) * width].copy_from_slice(&envs[j % 64]); }
+        let lens = vec![width as u32; n];
+        let mut oks = vec![0u8; n];
+        assert_eq!(unsafe { ffi::zkp_hip_verify_equality_batch(n as u64, buf.as_ptr(), width as u64, lens.as_ptr(), oks.as_mut_ptr()) }, 0, "{}", ffi::last_error());
+        assert!(oks.iter().all(|&x| x == 1), "a reference-made equality envelope was rejected inside a large batch");
+        let (bad, donor) = (5000usize, 5001usize);                   // envelope 5000 under its neighbour's commitment: every point still valid
+        let tail: Vec<u8> = buf[donor * width + 266..donor * width + 298].to_vec();
+        buf[bad * width + 266..bad * width + 298].copy_from_slice(&tail);
+        assert_eq!(unsafe { ffi::zkp_hip_verify_equality_batch(n as u64, buf.as_ptr(), width as u64, lens.as_ptr(), oks.as_mut_ptr()) }, 0);
+        let crossed = buf[bad * width..(bad + 1) * width].to_vec();
+        assert!(!equality_proof::verify_equality(crossed, 1000 + (bad % 64) as u64, 1000 + (bad % 64) as u64));
+        for j in 0..n { assert_eq!(oks[j] == 1, j != bad, "envelope {} of the large batch: HIP verdict {}", j, oks[j]); }
     }
 
     // negative cases of tests/integration.rs:72-91 against HIP envelopes
