@@ -18,7 +18,7 @@ struct EdGather {      // edwards25519, affine-Niels entries gathered per lane f
     // LDS by DMA 7.9, three waves with one step of lead 7.4, with two 7.5 (mixed batch: 12.6 / 12.4); the LDS-streamed radix-1024 kernel
     // this replaces: 9.6 (profiles/r04_edg_ab.jsonl)
     static constexpr uint32_t GATHER_WAVES = ZKP_EDG_WAVES; static constexpr int GATHER_PREFETCH = ZKP_EDG_PREFETCH;
-    static constexpr uint32_t GATHER_W = EDG_ENTRY_W, GATHER_STRIDE = EDG_SLOT_W;
+    static constexpr uint32_t GATHER_W = EDG_ENTRY_W, GATHER_STRIDE = EDG_SLOT_W, GATHER_PRIO = 0;
     using GAcc = ge;
     static __device__ __forceinline__ GAcc to_gather(const ge& a) { return a; }
     static __device__ __forceinline__ ge from_gather(const GAcc& a) { return a; }
@@ -28,6 +28,13 @@ struct EdGather {      // edwards25519, affine-Niels entries gathered per lane f
     static __device__ __forceinline__ Acc add(const Acc& a, const Acc& b) { return ge_add(a, b); }
 };
 template __global__ void k_msm_gather<EdGather>(MsmView, uint32_t, uint32_t);
+// The same kernel with its waves' issue priority raised (s_setprio; levels 1, 2 and 3 measured alike): for the chain's launches in a batch
+// that also holds Groth16 work, whose G1 / G2 gather waves share the SIMDs (batch_impl.inc).
+#ifndef ZKP_EDG_PRIO
+#define ZKP_EDG_PRIO 1
+#endif
+struct EdGatherPrio : EdGather { static constexpr uint32_t GATHER_PRIO = ZKP_EDG_PRIO; };
+template __global__ void k_msm_gather<EdGatherPrio>(MsmView, uint32_t, uint32_t);
 
 uint32_t edg_msm_rows_per_block() { return 256; }
 uint32_t edg_msm_blocks_per_cu() {
@@ -35,9 +42,10 @@ uint32_t edg_msm_blocks_per_cu() {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_msm_gather<EdGather>, 256, gather_lds_bytes<EdGather>()) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return occ > 0 ? (uint32_t)occ : 0;
 }
-void edg_launch_msm(const MsmView& m, uint32_t ngroups, uint32_t nblocks, hipStream_t st) {
+void edg_launch_msm(const MsmView& m, uint32_t ngroups, uint32_t nblocks, hipStream_t st, bool raised) {
     const uint32_t grid = ((nblocks + 7) / 8) * 8;
-    k_msm_gather<EdGather><<<grid, 256, gather_lds_bytes<EdGather>(), st>>>(m, ngroups, nblocks);
+    if (raised) k_msm_gather<EdGatherPrio><<<grid, 256, gather_lds_bytes<EdGather>(), st>>>(m, ngroups, nblocks);
+    else k_msm_gather<EdGather><<<grid, 256, gather_lds_bytes<EdGather>(), st>>>(m, ngroups, nblocks);
 }
 
 // ---- table construction (edg.h: steps 1-5)

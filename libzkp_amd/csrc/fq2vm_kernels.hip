@@ -104,6 +104,11 @@ int g16_vm_upload(G16VmTables& T) {          // (g16_vm_free is declared in g16_
         (void)hipGetLastError(); g16_vm_free(T); return -2;          // the 160 KB LDS opt-in of the Fq2 machine was refused: say so here, not as an opaque launch error later
     }
     for (auto& q : T.side) if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) rc = -1;
+    {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); greatest = 0; }
+        for (auto& q : T.vq) if (hipStreamCreateWithPriority(&q, hipStreamNonBlocking, greatest) != hipSuccess) rc = -1;
+    }
     for (auto& e : T.ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = -1;
     {
         // mask bit b = CU b / 8 of XCD b mod 8 (tools/cumask_probe.hip): bits 0..7 are the first CU of every XCD
@@ -120,6 +125,7 @@ void g16_vm_free(G16VmTables& T) {
     if (T.code) (void)hipFree((void*)T.code);
     if (T.off) (void)hipFree((void*)T.off);
     for (auto q : T.side) if (q) (void)hipStreamDestroy(q);
+    for (auto q : T.vq) if (q) (void)hipStreamDestroy(q);
     if (T.sub) (void)hipStreamDestroy(T.sub);
     if (T.tail) (void)hipStreamDestroy(T.tail);
     for (auto e : T.ev) if (e) (void)hipEventDestroy(e);
@@ -394,8 +400,8 @@ void g16_launch_verify_rlc(int kind, const uint8_t* d_in, uint64_t stride, const
     };
     // Streams.  st: parse | weighted points | chain A of the batch | product of its values | x V's value | V's finishing chain | verdict.
     // side[1] / sub: the subgroup chain of every B_j (a single round of chain A: from the parse on, beside the weighted points, which use no
-    // LDS; several rounds: after chain A, below).  side[0]: the scalar sums,
-    // V's fixed-base points, V's chain A.  side[2]: the sum of the w C, V's chain B.  The chains' workgroups hold 118 / 41 KB of LDS, and
+    // LDS; several rounds: after chain A, below).  vq[0] (greatest priority): the scalar sums,
+    // V's fixed-base points, V's chain A.  vq[1] (greatest priority): the sum of the w C, V's chain B.  The chains' workgroups hold 118 / 41 KB of LDS, and
     // whatever is launched behind a full grid of them waits for a CU to drain: when the batch's chain A is a single round of workgroups
     // (n <= 32 per CU) it is launched AFTER V's short kernels and one-workgroup chains have been placed -- V is the critical path there;
     // a longer chain A starts as soon as the weighted points exist and V's work (~8 ms) hides beneath it.
@@ -409,30 +415,32 @@ void g16_launch_verify_rlc(int kind, const uint8_t* d_in, uint64_t stride, const
         (void)hipEventRecord(T.ev[2], q);
     };
     if (!a_first) subgroup_chain(T.side[1]);
-    (void)hipStreamWaitEvent(T.side[0], T.ev[0], 0);
-    k_g16_rlc_terms<<<dim3(RLC_TERM_BLOCKS, vk.n_ic), 256, 0, T.side[0]>>>(kind, d_in, stride, d_len, n, vk, rho, flags, part);
-    k_g16_rlc_scalars<<<1, 256, 0, T.side[0]>>>(vk.n_ic, RLC_TERM_BLOCKS, part, scal);
-    k_g16_rlc_fixed<<<2, 256, 0, T.side[0]>>>(vk, scal, pts);
-    (void)hipEventRecord(T.ev[4], T.side[0]);
-    k_g16_rlc_virtual<<<1, 64, 0, T.side[0]>>>(vk, pts, iov, counters, 0u);
-    launch(0, 1, iov, nullptr, (uint32_t)(sizeof(fq2vm::SCRIPT_MILLER) / 2), T.side[0]);
-    (void)hipEventRecord(T.ev[1], T.side[0]);
+    (void)hipStreamWaitEvent(T.vq[0], T.ev[0], 0);
+    k_g16_rlc_terms<<<dim3(RLC_TERM_BLOCKS, vk.n_ic), 256, 0, T.vq[0]>>>(kind, d_in, stride, d_len, n, vk, rho, flags, part);
+    k_g16_rlc_scalars<<<1, 256, 0, T.vq[0]>>>(vk.n_ic, RLC_TERM_BLOCKS, part, scal);
+    k_g16_rlc_fixed<<<2, 256, 0, T.vq[0]>>>(vk, scal, pts);
+    (void)hipEventRecord(T.ev[4], T.vq[0]);
+    k_g16_rlc_virtual<<<1, 64, 0, T.vq[0]>>>(vk, pts, iov, counters, 0u);
+    launch(0, 1, iov, nullptr, (uint32_t)(sizeof(fq2vm::SCRIPT_MILLER) / 2), T.vq[0]);
+    (void)hipEventRecord(T.ev[1], T.vq[0]);
     k_g16_rlc_mul<<<dim3(nb, 2), 64, 0, st>>>(n, rho, acbuf, flags, io, cbuf);
     (void)hipEventRecord(T.ev[0], st);
     if (a_first) launch(0, n, io, nullptr, (uint32_t)(sizeof(fq2vm::SCRIPT_MILLER) / 2), st);
-    (void)hipStreamWaitEvent(T.side[2], T.ev[0], 0);
-    k_g1_sum<<<RLC_SUM_BLOCKS, 256, 0, T.side[2]>>>(cbuf, n, sums, RLC_SUM_BLOCKS);
-    k_g1_sum<<<1, 256, 0, T.side[2]>>>(sums, RLC_SUM_BLOCKS, pts + 60, 1);
-    (void)hipStreamWaitEvent(T.side[2], T.ev[4], 0);                 // (pts[0] = L_V comes from side[0])
-    k_g16_rlc_virtual<<<1, 64, 0, T.side[2]>>>(vk, pts, iov, counters, 1u);
-    launch(3, 1, iov + (size_t)fq2vm::PAIR_SLOTS * fq2vm::FQ2_W, d_lines, (uint32_t)(sizeof(fq2vm::SCRIPT_MILLER_B) / 2), T.side[2]);
-    (void)hipEventRecord(T.ev[3], T.side[2]);
+    (void)hipStreamWaitEvent(T.vq[1], T.ev[0], 0);
+    k_g1_sum<<<RLC_SUM_BLOCKS, 256, 0, T.vq[1]>>>(cbuf, n, sums, RLC_SUM_BLOCKS);
+    k_g1_sum<<<1, 256, 0, T.vq[1]>>>(sums, RLC_SUM_BLOCKS, pts + 60, 1);
+    (void)hipStreamWaitEvent(T.vq[1], T.ev[4], 0);                 // (pts[0] = L_V comes from vq[0])
+    k_g16_rlc_virtual<<<1, 64, 0, T.vq[1]>>>(vk, pts, iov, counters, 1u);
+    launch(3, 1, iov + (size_t)fq2vm::PAIR_SLOTS * fq2vm::FQ2_W, d_lines, (uint32_t)(sizeof(fq2vm::SCRIPT_MILLER_B) / 2), T.vq[1]);
+    (void)hipEventRecord(T.ev[3], T.vq[1]);
     if (!a_first) launch(0, n, io, nullptr, (uint32_t)(sizeof(fq2vm::SCRIPT_MILLER) / 2), st);
     const uint32_t* fin = io + (size_t)fq2vm::SLOT_F0 * fq2vm::FQ2_W * n;
     uint32_t* fv = iov + (size_t)fq2vm::SLOT_F0 * fq2vm::FQ2_W;
     // Several rounds of chain A: the subgroup chain runs AFTER it and the first product pass, beside the rest of the tail (V's finishing chain: ~4 ms on one CU; the subgroup chain's stream
     // leaves the first CU of every XCD free and the tail's stream is confined to those).  Beside chain A it only stretched it: both are bound by the SIMDs, not by LDS space -- 28.8 ms
-    // together against 21.4 + 5.6 ms one after the other at 65 536 envelopes.
+    // together against 21.4 + 5.6 ms one after the other at 65 536 envelopes.  (Also measured: the subgroup chain of the first 17 920 envelopes from the
+    // parse on, beside the weighted points, the rest after chain A -- the early part stretched the weighted points from 2.0 to 4.2 ms and the call
+    // took 35.75 against 35.9 ms: the same work on the same SIMDs in another order.)
     k_fq12_prod<<<RLC_PROD_BLOCKS, 64, 0, st>>>(fin, n, flags, prods, RLC_PROD_BLOCKS, nullptr);
     hipStream_t tq = st;
     if (a_first) { (void)hipEventRecord(T.ev[0], st); subgroup_chain(T.sub); tq = T.tail; (void)hipStreamWaitEvent(tq, T.ev[0], 0); }

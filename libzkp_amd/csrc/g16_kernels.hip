@@ -14,7 +14,7 @@ struct G1Msm {      // BN254 G1 key points (Groth16 a / b1 / h / l queries): pac
     static constexpr uint32_t GATHER_WAVES = ZKP_G1_GATHER_WAVES; static constexpr int GATHER_PREFETCH = ZKP_G1_GATHER_PREFETCH;      // k_msm_gather: 3 waves/SIMD, entries two steps ahead
     // the gather loop accumulates in XYZZ coordinates on nine 29-bit limbs (bn254_g.h: g1_mmadd9); the key tables hold the
     // nine-limb coordinates packed into eight words each (fq9_pack8): a 64-byte, 64-byte-aligned entry x | y (k_g16_build_table)
-    static constexpr uint32_t GATHER_W = 16, GATHER_STRIDE = 16;
+    static constexpr uint32_t GATHER_W = 16, GATHER_STRIDE = 16, GATHER_PRIO = 0;
     using GAcc = g1_xyzz9;
     static __device__ __forceinline__ GAcc to_gather(const g1_jac& a) { return xyzz9_from_jac(a); }
     static __device__ __forceinline__ g1_jac from_gather(const GAcc& a) { return jac_from_xyzz9(a); }
@@ -38,7 +38,7 @@ struct G2Msm {      // BN254 G2 (Fq2 coordinates), Groth16 b_g2_query
     static constexpr uint32_t GATHER_WAVES = 2; static constexpr int GATHER_PREFETCH = ZKP_G2_GATHER_PREFETCH;     // k_msm_gather: the addition itself takes ~240 VGPRs; entries one step ahead through LDS
     // the gather loop: XYZZ coordinates over Fq2 on nine 29-bit limbs (bn254_g.h: g2_mmadd9); table entries are the four
     // coordinates x.c0, x.c1, y.c0, y.c1 packed into eight words each: 128 bytes, one cache line
-    static constexpr uint32_t GATHER_W = 32, GATHER_STRIDE = 32;
+    static constexpr uint32_t GATHER_W = 32, GATHER_STRIDE = 32, GATHER_PRIO = 0;
     using GAcc = g2_xyzz9;
     static __device__ __forceinline__ GAcc to_gather(const g2_jac& a) { return g2_xyzz9_from_jac(a); }
     static __device__ __forceinline__ g2_jac from_gather(const GAcc& a) { return jac_from_g2_xyzz9(a); }

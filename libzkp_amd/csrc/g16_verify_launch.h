@@ -13,7 +13,8 @@ struct G16VmTables {
     const uint32_t *code = nullptr, *off = nullptr;                                 // four waves per chain (fq2vm_programs.h)
     const uint32_t* consts = nullptr;
     const uint16_t* script[4] = {nullptr, nullptr, nullptr, nullptr};               // chain A, subgroup, finish, chain B
-    hipStream_t side[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // chain B and the subgroup chain run beside chain A (the batch check uses the third)
+    hipStream_t side[2] = {nullptr, nullptr}; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // chain B and the subgroup chain run beside chain A
+    hipStream_t vq[2] = {nullptr, nullptr};        // the batch check's virtual envelope: greatest priority, so that its one-workgroup chains get the first CU that drains
     hipStream_t sub = nullptr, tail = nullptr;      // the batch check of several rounds: its subgroup chain on every CU but the first of each XCD, the one-workgroup tail (product, finishing chain) on those eight
     bool ready = false;
 };

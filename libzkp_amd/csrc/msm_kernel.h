@@ -101,6 +101,7 @@ __global__ void __launch_bounds__(256, T::GATHER_WAVES) k_msm_gather(MsmView m, 
             if ((uint32_t)k < left) { const uint2 ds = steps[k]; dd[k] = T::digit(qpre[k], ds.y & 1u); fetch(e[k], ds, dd[k]); }
         }
         uint32_t q0 = qpre[LEAD], q1 = qpre[LEAD + 1];
+        if constexpr (T::GATHER_PRIO > 0) __builtin_amdgcn_s_setprio(T::GATHER_PRIO);          // issue priority over co-resident waves from here on
         for (uint32_t i = 0; i < left; i++) {
             dd[LEAD] = 0;
             if (i + LEAD < left) { const uint2 ds = steps[i + LEAD]; dd[LEAD] = T::digit(q0, ds.y & 1u); fetch(e[LEAD], ds, dd[LEAD]); }

@@ -301,6 +301,7 @@ struct Device {
     bool ready = false;
     uint64_t generation = 0;            // bumped by zkp_hip_shutdown: staged batches of an earlier life own nothing any more
     int num_cu = 256;
+    int msm_prio_now = 0;               // set by the mixed-batch scheduler while it enqueues the Bulletproofs chain of a batch that also holds Groth16 work: the ed25519 MSM waves raise their issue priority
     int cus_now = 0;                    // CUs the launches being enqueued may use (0 = all): set by the mixed-batch scheduler while it enqueues a variant on CU-masked streams
     std::vector<SubBatch> subm;         // [lane]: Bulletproofs streams + workspace confined to the Bulletproofs CU partition of a mixed batch
     hipStream_t stream = nullptr;
@@ -793,7 +794,7 @@ int launch_msm(const DevLayout& D, uint32_t rows, const uint32_t* digits, uint32
         m.nwin = EDG_NWIN; m.nent = EDG_NENT; m.digw = DIGW; m.slot_ent = EDG_NWIN * EDG_NENT; m.uneven = 0;
         m.steps = D.steps; m.chunk_step0 = D.chunk_step0;
         const uint32_t tb = edg_msm_rows_per_block(), ngroups = (rows + tb - 1) / tb, nblocks = D.nchunks * ngroups;
-        ZKP_TRACED("k_msm_gather<EdGather>", st, edg_launch_msm(m, ngroups, nblocks, st));
+        ZKP_TRACED("k_msm_gather<EdGather>", st, edg_launch_msm(m, ngroups, nblocks, st, dev().msm_prio_now != 0));
     }
     prof_end(dev().prof[0], st, e1, D.adds_per_row * rows);
     return 0;
@@ -1133,6 +1134,7 @@ void zkp_hip_shutdown(void) try {
             vec->clear();
         }
         d->cus_now = 0;
+        d->msm_prio_now = 0;
         release_edg_table();
         free_set(d->p2); free_set(d->ct);
         for (auto& F : d->fam) { free_set(F.p1); for (auto& s : F.rd) free_set(s); F.ready = false; }

@@ -1,7 +1,8 @@
 # Round-4 profile set of the default bench command (run on the GPU box through gpurun: `bash tools/profile_round.sh`).
 # kt:    kernel trace + stats of the overlapped run (B = python3 bench.py --steps N --warmup 1 --no-cpu-baseline --no-extra-legs)
 # pmc_*: separate counter passes (they serialise the dispatches: every kernel alone on the GPU) -- SQ issue/wait, LDS, FETCH_SIZE, WRITE_SIZE, read requests
-# then the library's own launch trace (ZKP_HIP_TRACE: a timeline without the profiler's per-dispatch host cost) and the default bench line.
+# then the library's own launch trace (ZKP_HIP_TRACE: a timeline without the profiler's per-dispatch host cost), the verification sweeps (row N2) and the
+# default bench line (which reads the kernel_alone / traffic files this very run has just produced: they are copied into profiles/ on the box first).
 cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && O=$R/gpurun_out/r4v && mkdir -p $O && cd $R \
 && rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra-legs > $O/bench_under_rocprof.json 2>$O/err_kt.txt \
 && python3 tools/timeline.py $O/kt/p_kernel_trace.csv > $O/timeline_rocprof.txt \
@@ -18,4 +19,8 @@ cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && O=$R/gpurun_out/r4v && mk
 && rm -f $O/trace.jsonl && ZKP_HIP_TRACE=$O/trace.jsonl python3 tools/enqueue_time.py 4096 7 > $O/enqueue_traced.txt 2>&1 \
 && python3 tools/trace_timeline.py $O/trace.jsonl > $O/timeline_trace.txt \
 && python3 tools/enqueue_time.py 4096 21 > $O/enqueue.txt 2>&1 \
+&& cp $O/kernel_alone.csv $R/profiles/r04_kernel_alone.csv && cp $O/kernel_alone.meta.json $R/profiles/r04_kernel_alone.meta.json && cp $O/traffic.json $R/profiles/r04_traffic.json \
+&& python3 tools/verify_g16_time.py 4096 --sweep > $O/verify_g16.json 2>$O/err_vg.txt \
+&& python3 tools/verify_g16_batch_sweep.py > $O/verify_g16_batch.json 2>$O/err_vgb.txt \
+&& python3 tools/bench_verify.py > $O/verify_rates.json 2>$O/err_vr.txt \
 && python3 bench.py > $O/bench.json 2>$O/err_bench.txt && tail -n 1 $O/bench.json | cut -c1-300 && rm -f $O/*/p_agent_info.csv $O/pmc_*/p_kernel_trace.csv $O/kt/p_kernel_trace.csv && ls $O $O/pmc_s | head -40
