@@ -9,7 +9,9 @@ from collections import defaultdict
 
 def short(name):
     n = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    return n.split("(")[0].replace(", 8u, 256u, 1u", "").replace(", 32u, 256u, 1u", "").strip()
+    n = n.split("(")[0].replace(", 8u, 256u, 1u", "").replace(", 32u, 256u, 1u", "").strip()
+    # k_msm_gather<EdGatherPrio> is k_msm_gather<EdGather> with its waves' issue priority raised (mixed batches): one row, the kernel's name
+    return n.replace("k_msm_gather<EdGatherPrio>", "k_msm_gather<EdGather>")
 
 
 def main():
@@ -24,8 +26,8 @@ def main():
         w = csv.writer(f)
         w.writerow(["kernel", "avg_ms", "launches_per_step", "ms_per_step", "launches"])
         for k in sorted(tot, key=lambda k: -tot[k]):
-            if k.startswith("k_g16_build_table") or k.startswith("__amd"):
-                continue                                      # key load / runtime copies: not part of a step
+            if k.startswith("k_g16_build_table") or k.startswith("k_edg_") or k.startswith("__amd"):
+                continue                                      # key load / generator-table build / runtime copies: not part of a step
             w.writerow([k, "%.4f" % (tot[k] / cnt[k]), "%.3f" % (cnt[k] / steps), "%.4f" % (tot[k] / steps), cnt[k]])
     # sidecar: the kernel sources this pass was taken on (bench.py marks the figures stale when they have changed since)
     import hashlib, json, os

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp && R=$GRAFT_REPO_ROOT && O=$R/gpurun_out/r4v && mk
 && python3 tools/kernel_alone.py $O/pmc_s/p_kernel_trace.csv $O/kernel_alone.csv \
 && python3 tools/traffic_json.py $O/traffic.json "k_msm_gather<G1Msm>" $O/pmc_f/p_counter_collection.csv $O/pmc_w/p_counter_collection.csv "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_RDREQ_sum passes of 'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs' (tools/profile_round.sh), averaged over the G1 MSM launches of the run" 64 $O/pmc_r/p_counter_collection.csv > /dev/null \
 && python3 tools/traffic_json.py $O/traffic_g2.json "k_msm_gather<G2Msm>" $O/pmc_f/p_counter_collection.csv $O/pmc_w/p_counter_collection.csv "same passes, the G2 MSM launches" 128 $O/pmc_r/p_counter_collection.csv > /dev/null \
-&& python3 tools/traffic_json.py $O/traffic_ed.json "k_msm_gather<EdGather>" $O/pmc_f/p_counter_collection.csv $O/pmc_w/p_counter_collection.csv "same passes, the ed25519 MSM launches" 128 $O/pmc_r/p_counter_collection.csv > /dev/null \
+&& python3 tools/traffic_json.py $O/traffic_ed.json "k_msm_gather<EdGather" $O/pmc_f/p_counter_collection.csv $O/pmc_w/p_counter_collection.csv "same passes, the ed25519 MSM launches" 128 $O/pmc_r/p_counter_collection.csv > /dev/null \
 && python3 tools/summarize_profile.py $O/summary.md $O/kt/p_kernel_stats.csv $O/pmc_s/p_counter_collection.csv $O/pmc_l/p_counter_collection.csv $O/pmc_f/p_counter_collection.csv $O/pmc_w/p_counter_collection.csv $O/pmc_r/p_counter_collection.csv \
 && rm -f $O/trace.jsonl && ZKP_HIP_TRACE=$O/trace.jsonl python3 tools/enqueue_time.py 4096 7 > $O/enqueue_traced.txt 2>&1 \
 && python3 tools/trace_timeline.py $O/trace.jsonl > $O/timeline_trace.txt \
