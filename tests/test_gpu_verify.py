@@ -444,3 +444,7 @@ def test_groth16_one_pairing_check_per_batch_gives_the_per_envelope_verdicts(hip
     big[5000] = big[5000][:266] + big[5001][266:]
     got = api._verify_snark_envelopes(0, big)
     assert got.count(False) == 1 and got[5000] is False
+    # nothing but refused envelopes: no live envelope, the virtual envelope has no points -- the call still answers (all rejected)
+    assert api._verify_snark_envelopes(0, [bytes(298)] * 8200) == [False] * 8200
+    mixed = [proofs[i % 150] if i % 2 else bytes(298) for i in range(8200)]
+    assert api._verify_snark_envelopes(0, mixed) == [bool(i % 2) for i in range(8200)]
