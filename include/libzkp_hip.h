@@ -161,7 +161,10 @@ int zkp_hip_prove_improvement_batch_device(uint64_t n, const uint64_t* d_old, co
  * the loaded proving key (zkp_hip_groth16_load_key / _generate_key): SnarkBackend::verify_equality_zk (snark.rs:377-401) and
  * verify_membership_zk (snark.rs:455-495) as reached from verify_proof_cryptographic (proof_helpers.rs:180-206).  The public
  * inputs are the envelope's own commitment (and embedded set); callers compare those with what they expect, as
- * equality_proof.rs:34-60 / set_membership.rs:40-70 do.  ok[i] = 1 accepted / 0 rejected. */
+ * equality_proof.rs:34-60 / set_membership.rs:40-70 do.  ok[i] = 1 accepted / 0 rejected.
+ * Calls with more than 8192 envelopes first try ONE weighted pairing check for all of them (fresh 128-bit weights from getrandom;
+ * libzkp_amd/csrc/g16_rlc.h) and verify envelope by envelope only if it does not stand, so every verdict is the per-envelope one up to a
+ * soundness error of 2^-128 per call; ZKP_HIP_NO_BATCH_VERIFY=1 / ZKP_HIP_G16_BATCH_VERIFY_MIN move or remove the threshold. */
 int zkp_hip_verify_equality_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, const uint32_t* lens, uint8_t* ok);
 int zkp_hip_verify_membership_batch(uint64_t n, const uint8_t* proofs, uint64_t stride, const uint32_t* lens, uint8_t* ok);
 
