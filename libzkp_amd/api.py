@@ -461,7 +461,7 @@ def _verify_snark_envelopes(kind, blobs):
     ok = np.zeros(n, dtype=np.uint8)
     fn = _native.lib().zkp_hip_verify_equality_batch if kind == 0 else _native.lib().zkp_hip_verify_membership_batch
     _native.check(fn(n, _P(buf), stride, _P(lens), _P(ok)), "zkp_hip_verify_%s_batch" % ("equality" if kind == 0 else "membership"))
-    return [bool(x) for x in ok]
+    return ok.astype(bool).tolist()
 
 
 def verify_equality_with_commitment_batch(proofs, commitments):
@@ -516,7 +516,7 @@ def verify_consistency_batch(proofs):
     buf, lens, stride = _rows(blobs, 1 << 20)
     ok = np.zeros(n, dtype=np.uint8)
     _native.check(_native.lib().zkp_hip_verify_consistency_batch(n, _P(buf), stride, _P(lens), _P(ok)), "zkp_hip_verify_consistency_batch")
-    return [bool(x) for x in ok]
+    return ok.astype(bool).tolist()
 
 
 def verify_consistency(proof):
@@ -535,7 +535,7 @@ def verify_improvement_batch(proofs, olds):
     buf, lens, stride = _rows(blobs, 8192)
     ok = np.zeros(n, dtype=np.uint8)
     _native.check(_native.lib().zkp_hip_verify_improvement_batch(n, _P(buf), stride, _P(lens), _P(ov), _P(ok)), "zkp_hip_verify_improvement_batch")
-    return [bool(x) for x in ok]
+    return ok.astype(bool).tolist()
 
 
 def verify_improvement(proof, old):
